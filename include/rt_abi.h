@@ -1,0 +1,283 @@
+/* rt_abi.h -- C ABI of the MI355X path-tracing library (librt_hip.so).
+ *
+ * The reference crate has no FFI layer: its public Rust API is the boundary.
+ * The entry points below are what a Rust facade crate (or any other host)
+ * binds in place of the reference's render loop.  Each one names the
+ * reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C structs, pointers and sizes; no C++ or torch types;
+ *   - the library copies every array of a scene description during
+ *     rt_scene_create(); the caller may free its arrays on return;
+ *   - every function returns an rt_status and never aborts across the ABI;
+ *     rt_last_error() returns a thread-local message for the last failure;
+ *   - "device" pointers are HIP device addresses on the scene's device;
+ *   - a scene handle is immutable after creation; rendering calls that share a
+ *     handle must not overlap (they share the handle's device workspace).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = 1, /* null pointer, bad index, width/height < 2, empty shutter interval ... */
+    RT_ERR_EMPTY_SCENE = 2,      /* Scene::new asserts !objects.is_empty() (src/lib.rs:161) */
+    RT_ERR_UNSUPPORTED = 3,      /* description uses something the kernels do not implement */
+    RT_ERR_NO_DEVICE = 4,        /* no usable HIP device */
+    RT_ERR_HIP = 5,              /* a HIP runtime call failed; see rt_last_error() */
+    RT_ERR_OUT_OF_MEMORY = 6
+} rt_status;
+
+/* ---------------------------------------------------------------- scene
+ * Flattened form of `Scene { objects: BvhNode<Object>, background_color }`
+ * (src/lib.rs:119-133): one rt_prim per `Object` (src/lib.rs:261-266), in the
+ * order of the `Vec<Object>` given to Scene::new; the index in that list is the
+ * primitive id used for RNG keying and reported in hit records.
+ */
+
+/* Innermost geometry of a `Shape` (src/geometry/shape.rs:62-106) once the
+ * Flipped / Translated / Rotated / ConstantMedium wrappers are peeled off. */
+enum { RT_GEOM_SPHERE = 0, RT_GEOM_MOVING_SPHERE = 1, RT_GEOM_RECT = 2, RT_GEOM_BOX = 3 };
+
+enum {
+    RT_PRIM_FLIP = 1u,   /* odd number of Shape::Flipped wrappers (outside the medium, if any) */
+    RT_PRIM_MEDIUM = 2u, /* Shape::ConstantMedium { boundary, density } */
+    RT_PRIM_INERT = 4u   /* provably never hit (a medium whose boundary is a sphere: the second
+                            boundary query of shape.rs:390 repeats the near root); kept in the
+                            list so primitive ids stay stable, left out of the BVH */
+};
+
+typedef struct rt_prim {
+    uint8_t geom;       /* RT_GEOM_* ; index space of `geom_index` */
+    uint8_t flags;      /* RT_PRIM_* */
+    uint16_t xf_count;  /* rigid wrappers, outermost first */
+    uint32_t xf_first;  /* first element in rt_scene_desc.xforms */
+    uint32_t geom_index;
+    uint32_t material;
+    float density;      /* medium only */
+    uint32_t xf_outer;  /* medium only: how many of the wrappers sit outside the ConstantMedium */
+    uint32_t reserved[2];
+} rt_prim; /* 32 bytes */
+
+/* Sphere { center, radius } and MovingSphere { ray, radius, start_time, .. }
+ * (shape.rs:64-73).  Kept in f64: the discriminant half_b^2 - a*c (shape.rs:265)
+ * cancels catastrophically in fp32 for the radius-1000 spheres of the examples. */
+typedef struct rt_sphere {
+    double center[3]; /* MovingSphere: ray.origin = centre at start_time */
+    double radius;
+    double motion[3]; /* MovingSphere: ray.direction = end_center - start_center; else 0 */
+    double start_time;
+} rt_sphere; /* 64 bytes */
+
+/* Rectangle { axis, lower_left, upper_right, height } (shape.rs:77-82). */
+typedef struct rt_rect {
+    uint32_t axis; /* 0 X, 1 Y, 2 Z: the axis orthogonal to the rectangle */
+    float x0, y0, x1, y1, height;
+    uint32_t reserved[2];
+} rt_rect; /* 32 bytes */
+
+/* Box { min, max, sides } (shape.rs:88-92); the six sides are those of
+ * Shape::new_box (shape.rs:157-215), in that order. */
+typedef struct rt_box {
+    float min[3];
+    float max[3];
+    uint32_t reserved[2];
+} rt_box; /* 32 bytes */
+
+/* One rigid wrapper: Translated { offset } (shape.rs:98) or Rotated { axis,
+ * angle } (shape.rs:101-105) with cos/sin of +angle precomputed in f64. */
+enum { RT_XF_TRANSLATE = 0, RT_XF_ROTATE_X = 1, RT_XF_ROTATE_Y = 2, RT_XF_ROTATE_Z = 3 };
+typedef struct rt_xform {
+    uint32_t kind;
+    float a, b, c; /* translate: offset xyz; rotate: a = cos(angle), b = sin(angle), c unused */
+} rt_xform;        /* 16 bytes */
+
+/* Material (src/materials.rs:8-18). */
+enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3, RT_MAT_ISOTROPIC = 4 };
+typedef struct rt_material {
+    uint32_t kind;
+    uint32_t texture; /* Lambertian / DiffuseLight / Isotropic */
+    float albedo[3];  /* Metal / Dielectric */
+    float param;      /* Metal: fuzz; Dielectric: refraction_index */
+    uint32_t reserved[2];
+} rt_material; /* 32 bytes */
+
+/* Texture (src/textures.rs:8-19). */
+enum { RT_TEX_SOLID = 0, RT_TEX_CHECKERED = 1, RT_TEX_NOISE = 2, RT_TEX_IMAGE = 3 };
+typedef struct rt_texture {
+    uint32_t kind;
+    float color[3];    /* SolidColor */
+    uint32_t odd, even;/* Checkered: indices of the two child textures */
+    float scale;       /* Noise */
+    uint32_t resource; /* Noise: permutation table index; Image: image index */
+} rt_texture;          /* 32 bytes */
+
+/* Image(RgbImage) (textures.rs:18): 8-bit RGB, row 0 at the top, 3 bytes per texel. */
+typedef struct rt_image {
+    uint32_t width, height;
+    uint64_t texel_offset; /* byte offset into rt_scene_desc.texels */
+} rt_image;
+
+/* Linearised BVH in depth-first pre-order with skip links (stackless traversal).
+ *
+ * The reference's BvhNode::scatter_ (src/lib.rs:228-257) visits left then right with a
+ * shrinking tmax and tests each node's box first, so what it computes is a scan over the
+ * LEAVES IN DEPTH-FIRST ORDER: a leaf's object is tried iff the ray overlaps the leaf's box
+ * within (tmin, current tmax); an accepted hit lowers tmax.  That order is observable: the
+ * y-sides of Shape::new_box carry their x and z extents swapped (shape.rs:180-195 against
+ * :315-328), so a box can be hit outside its own bounding box, and whether such a hit counts
+ * depends on the leaf test and on the hits found before it.  The host therefore builds the
+ * tree exactly as BvhNode::create_ does (src/lib.rs:160-200: random axis, stable sort by
+ * bound().min[axis], split at n/2) and the kernels walk it in the same order.
+ *
+ * Node i's subtree is nodes [i+1, skip); a leaf has prim != RT_BVH_NONE and skip == i+1.
+ * Inner boxes must contain the boxes of the leaves below them (they may be wider).  Inert
+ * primitives are left out.
+ *
+ * A leaf whose prim field carries RT_BVH_EXACT holds the primitive's exact bound() box and is
+ * tested the way BoundingBox::hit does it (shape.rs:580-599: t = (bound - origin) / direction,
+ * miss when tmax <= tmin).  The host sets it on every box-shaped primitive: their leaf test is
+ * observable (hits outside the box; the strict test is what decides between two boxes that
+ * share a face).  All other boxes are widened and tested conservatively. */
+#define RT_BVH_NONE 0xFFFFFFFFu
+#define RT_BVH_EXACT 0x80000000u
+typedef struct rt_bvh_node {
+    float min[3];
+    uint32_t skip; /* index of the next node in pre-order that is not in this node's subtree */
+    float max[3];
+    uint32_t prim; /* leaf: primitive id (| RT_BVH_EXACT); inner node: RT_BVH_NONE */
+} rt_bvh_node;     /* 32 bytes */
+
+typedef struct rt_scene_desc {
+    uint32_t abi_version; /* RT_ABI_VERSION */
+    uint32_t n_prims, n_spheres, n_rects, n_boxes, n_xforms, n_materials, n_textures, n_images, n_perm_tables, n_bvh_nodes;
+    uint32_t reserved0;
+    const rt_prim* prims;
+    const rt_sphere* spheres;
+    const rt_rect* rects;
+    const rt_box* boxes;
+    const rt_xform* xforms;
+    const rt_material* materials;
+    const rt_texture* textures;
+    const rt_image* images;
+    const uint8_t* texels;
+    uint64_t texel_bytes;
+    const uint8_t* perm_tables; /* n_perm_tables x 256 bytes */
+    const rt_bvh_node* bvh;
+    double background[3]; /* Scene.background_color */
+} rt_scene_desc;
+
+#define RT_MAX_XFORMS_PER_PRIM 8u
+#define RT_MAX_TEXTURE_NESTING 8u
+
+/* `Camera` (src/lib.rs:314-341) after Camera::new (src/lib.rs:347-384), computed by the host in f64. */
+typedef struct rt_camera {
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3];
+    double u[3], v[3]; /* onb[0], onb[1] */
+    double lens_radius, shutter_open, shutter_close;
+} rt_camera;
+
+/* `ImageOptions` (src/lib.rs:108-117), same four fields. */
+typedef struct rt_image_options {
+    uint32_t height, width;
+    uint64_t samples_per_pixel, max_reflections;
+} rt_image_options;
+
+/* No counterpart in the reference (it has neither seeds nor devices). */
+typedef struct rt_render_options {
+    uint64_t seed;            /* keys the Philox streams (pixel, sample, bounce, stream) */
+    uint32_t rank, world_size;/* this process renders the tiles with tile_id % world_size == rank */
+    uint32_t tile_w, tile_h;  /* 0 = default 16 x 16 */
+    uint32_t samples_per_pass;/* 0 = automatic; does not change the result */
+    uint32_t flags;           /* RT_RENDER_* */
+    void* stream;             /* hipStream_t to launch on; NULL = the library's own stream */
+} rt_render_options;
+enum {
+    RT_RENDER_PROFILE = 1u,  /* time every kernel launch with HIP events (rt_get_profile) */
+    RT_RENDER_NO_TAIL = 2u,  /* every bounce as separate traverse / shade launches (same image; for tests) */
+    RT_RENDER_TAIL_ONLY = 4u /* every path runs start to end in the tail kernel (same image; for tests) */
+};
+
+typedef struct rt_scene rt_scene; /* opaque */
+
+/* Replaces Scene::new(objects, background, rng) (src/lib.rs:127-132): uploads the
+ * flattened scene to HIP device `device` (-1 = current device). */
+rt_status rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Replaces `pixels(&camera, &scene, image_options) -> Vec<u8>` (src/lib.rs:18-32).
+ * rgb_out: 3*width*height bytes, caller-owned host memory, row-major, top row first.
+ * mean_out (optional): 3*width*height doubles, mean linear radiance per channel before
+ * the clamp / sqrt / *255.999 quantisation of src/lib.rs:68-72.
+ * With world_size > 1 only the pixels of this rank's tiles are rendered; the others are
+ * written as 0 (sum the outputs of all ranks, then quantise with rt_quantise). */
+rt_status rt_render(rt_scene* scene, const rt_camera* camera, const rt_image_options* image_options,
+                    const rt_render_options* render_options, uint8_t* rgb_out, double* mean_out);
+
+/* Same computation with the result left on the device: d_mean_out is a device buffer of
+ * 3*width*height doubles (pixels of other ranks' tiles are written as 0).  Returns after
+ * the work is enqueued on the stream; the caller synchronises. */
+rt_status rt_render_device(rt_scene* scene, const rt_camera* camera, const rt_image_options* image_options,
+                           const rt_render_options* render_options, double* d_mean_out);
+
+/* The per-pixel quantisation of src/lib.rs:68-72 ("max(0).min(1).sqrt() * 255.999 as u8")
+ * on a device buffer of n doubles -> n bytes (device), enqueued on `stream`. */
+rt_status rt_quantise_device(rt_scene* scene, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream);
+
+/* Parity hook for `Intersection::intersect(&self, ray, (tmin, tmax), time)`
+ * (src/geometry/shape.rs:14) and for the closest hit of BvhNode::scatter_
+ * (src/lib.rs:228-257). */
+typedef struct rt_ray {
+    float origin[3];
+    float direction[3];
+    float time;
+} rt_ray;
+typedef struct rt_hit { /* IntersectionPoint, shape.rs:539-550 */
+    int32_t hit;
+    uint32_t prim;
+    float t;
+    float point[3], normal[3], in_vec[3];
+    float u, v;
+} rt_hit;
+/* scope < 0: closest hit over the whole scene through the BVH; scope >= 0: that primitive
+ * alone.  medium_u (optional, n floats): the uniform variate every ConstantMedium uses
+ * for ray i; when NULL it is Philox(seed; pixel = i, sample 0, bounce 0, stream 1 + prim).
+ * rays / medium_u / out are host pointers. */
+rt_status rt_intersect_batch(rt_scene* scene, int64_t scope, const rt_ray* rays, uint64_t n, float tmin, float tmax,
+                             uint64_t seed, const float* medium_u, rt_hit* out);
+
+/* Camera rays exactly as pixel() draws them (src/lib.rs:55-60, :389-401) for n
+ * (column i, row-from-bottom j, sample) triples; host pointers. */
+rt_status rt_camera_rays(rt_scene* scene, const rt_camera* camera, const rt_image_options* image_options, uint64_t seed,
+                         uint64_t n, const uint32_t* px_i, const uint32_t* px_j, const uint32_t* sample, rt_ray* out);
+
+/* Kernel timings of the last rt_render / rt_render_device call made with RT_RENDER_PROFILE. */
+enum { RT_K_RAYGEN = 0, RT_K_TRAVERSE = 1, RT_K_SHADE = 2, RT_K_TAIL = 3, RT_K_RESOLVE = 4, RT_K_FINALIZE = 5, RT_K_COUNT = 6 };
+typedef struct rt_profile {
+    double kernel_ms[RT_K_COUNT];      /* sum of launch durations, HIP events on the launch stream */
+    uint64_t kernel_launches[RT_K_COUNT];
+    uint64_t samples;                  /* camera paths started */
+    uint64_t segments;                 /* path segments traced (ray queries) */
+    uint64_t traverse_segments;        /* segments handled by the stand-alone traverse kernel */
+    uint64_t passes;
+} rt_profile;
+rt_status rt_get_profile(rt_scene* scene, rt_profile* out);
+
+/* Number of HIP devices visible to the library (0 when there is none). */
+int rt_device_count(void);
+const char* rt_last_error(void);
+uint32_t rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

@@ -1,0 +1,533 @@
+// rt_core.h -- per-ray arithmetic of the path tracer: intersection, BVH
+// traversal, materials, textures, camera, Philox.  Everything here is a
+// function of plain values and read-only scene arrays, marked RT_HD so that the
+// HIP kernels (rt_kernels.hip) are its only product consumer while a g++ build
+// of the same functions serves the CPU-side unit tests.
+//
+// Arithmetic is fp32 with two exceptions, both because the reference computes
+// in f64 throughout (src/geometry.rs:74) and fp32 would not hold 1e-5 relative
+// agreement: sphere intersection (the discriminant of shape.rs:265 cancels for
+// the radius-1000 spheres) and primary-ray generation.  Built with
+// -ffp-contract=off; fused multiply-adds are written explicitly so that every
+// kernel that inlines these functions produces the same bits.
+#ifndef RT_CORE_H
+#define RT_CORE_H
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/rt_abi.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+#define RT_PI_F 3.14159265358979323846f
+#define RT_PI_D 3.14159265358979323846
+#define RT_INF_F (__builtin_inff())
+#define RT_TAG_CAMERA 0xFFFFFFFFu
+
+struct V3 { float x, y, z; };
+RT_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+RT_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+RT_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+RT_HD float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+RT_HD float norm(V3 a) { return sqrtf(dot(a, a)); }
+RT_HD V3 normed(V3 a) { return a / norm(a); }  // geometry.rs:102: NaN for the zero vector
+RT_HD float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+RT_HD V3 madd(V3 o, V3 d, float t) { return v3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)); }
+// Ray::at (geometry.rs:340-346): t <= 0 returns the origin.
+RT_HD V3 ray_at(V3 o, V3 d, float t) { return (t <= 0.0f) ? o : madd(o, d, t); }
+
+struct D3 { double x, y, z; };
+RT_HD D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD D3 d3(V3 a) { return d3((double)a.x, (double)a.y, (double)a.z); }
+RT_HD D3 d3(const double* p) { return d3(p[0], p[1], p[2]); }
+RT_HD D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD D3 operator*(D3 a, double s) { return d3(a.x * s, a.y * s, a.z * s); }
+RT_HD double dot(D3 a, D3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+RT_HD V3 v3(D3 a) { return v3((float)a.x, (float)a.y, (float)a.z); }
+
+// Rotation about a coordinate axis (geometry.rs:33-50): (c0,c1) = X:(1,2) Y:(2,0) Z:(0,1);
+// out[c0] = s[c0] cos - s[c1] sin; out[c1] = s[c0] sin + s[c1] cos.
+RT_HD V3 rotate_cs(V3 s, uint32_t kind, float c, float sn) {
+    V3 o = s;
+    if (kind == RT_XF_ROTATE_X) { o.y = fmaf(s.y, c, -(s.z * sn)); o.z = fmaf(s.y, sn, s.z * c); }
+    else if (kind == RT_XF_ROTATE_Y) { o.z = fmaf(s.z, c, -(s.x * sn)); o.x = fmaf(s.z, sn, s.x * c); }
+    else { o.x = fmaf(s.x, c, -(s.y * sn)); o.y = fmaf(s.x, sn, s.y * c); }
+    return o;
+}
+
+// ------------------------------------------------------------------ Philox
+struct U4 { uint32_t x, y, z, w; };
+RT_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += W0; k1 += W1;
+    }
+    U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
+}
+// 24-bit uniform in [0,1), exact in fp32.
+RT_HD float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// Identity of the path segment being traced; keys every random draw.
+struct DrawKey {
+    uint32_t k0, k1;  // render seed
+    uint32_t pixel, sample, bounce;
+    float medium_u;   // >= 0: injected variate used by every medium (parity hook)
+};
+RT_HD float medium_variate(const DrawKey& k, uint32_t prim) {
+    if (k.medium_u >= 0.0f) return k.medium_u;
+    return u01(philox4x32_10(k.pixel, k.sample, k.bounce, 1u + prim, k.k0, k.k1).x);
+}
+
+// --------------------------------------------------------------- the scene
+struct SceneView {
+    const rt_prim* prims; const rt_sphere* spheres; const rt_rect* rects; const rt_box* boxes; const rt_xform* xforms;
+    const rt_material* materials; const rt_texture* textures; const rt_image* images; const uint8_t* texels;
+    const uint8_t* perm; const rt_bvh_node* bvh;
+    uint32_t n_prims, n_bvh_nodes;
+    float background[3];
+};
+
+RT_HD void axis_perm(uint32_t axis, int& p1, int& p2, int& o) {  // shape.rs:138-142
+    if (axis == 0) { p1 = 1; p2 = 2; o = 0; } else if (axis == 1) { p1 = 2; p2 = 0; o = 1; } else { p1 = 0; p2 = 1; o = 2; }
+}
+
+// Ray into the frame of the innermost shape: Translated subtracts the offset
+// from the origin (shape.rs:356-360), Rotated rotates origin and direction by
+// -angle (shape.rs:370-374); wrappers are applied outermost first.
+RT_HD void to_local(const SceneView& S, const rt_prim& P, V3& o, V3& d) {
+    for (uint32_t k = 0; k < P.xf_count; ++k) {
+        const rt_xform X = S.xforms[P.xf_first + k];
+        if (X.kind == RT_XF_TRANSLATE) o = o - v3(X.a, X.b, X.c);
+        else { o = rotate_cs(o, X.kind, X.a, -X.b); d = rotate_cs(d, X.kind, X.a, -X.b); }
+    }
+}
+
+// Sphere / MovingSphere, near root only (shape.rs:256-307), in f64.
+RT_HD D3 sphere_center(const rt_sphere& sp, bool moving, float time) {
+    D3 c = d3(sp.center);
+    if (moving) {
+        double dt = (double)time - sp.start_time;  // MovingSphere: ray.at(time - start_time), clamped at <= 0
+        if (!(dt <= 0.0)) c = c + d3(sp.motion) * dt;
+    }
+    return c;
+}
+// Near root (-half_b - sqrt(disc)) / a of shape.rs:262-270; false when the discriminant is negative.
+RT_HD bool sphere_root(const rt_sphere& sp, bool moving, V3 o, V3 d, float time, double& t_out) {
+    D3 c = sphere_center(sp, moving, time);
+    D3 oc = d3(o) - c, dd = d3(d);
+    double a = dot(dd, dd);
+    double half_b = dot(oc, dd);
+    double cc = dot(oc, oc) - sp.radius * sp.radius;
+    double disc = half_b * half_b - a * cc;
+    if (disc < 0.0) return false;
+    t_out = (-half_b - sqrt(disc)) / a;
+    return true;
+}
+RT_HD bool sphere_t(const rt_sphere& sp, bool moving, V3 o, V3 d, float tmin, float tmax, float time, double& t_out) {
+    double t;
+    if (!sphere_root(sp, moving, o, d, time, t)) return false;
+    if (t > (double)tmin && t < (double)tmax) { t_out = t; return true; }  // strict on both ends (shape.rs:271)
+    return false;
+}
+
+// Rectangle (shape.rs:309-332): inclusive interval and extents tests written so
+// that NaN and infinity flow exactly as in the reference.
+RT_HD bool rect_t(uint32_t axis, float x0, float y0, float x1, float y1, float height, V3 o, V3 d, float tmin, float tmax, float& t_out) {
+    int p1, p2, oo; axis_perm(axis, p1, p2, oo);
+    float t = (height - comp(o, oo)) / comp(d, oo);
+    if (t < tmin || t > tmax) return false;
+    V3 pt = ray_at(o, d, t);
+    float a = comp(pt, p1), b = comp(pt, p2);
+    if (a < x0 || a > x1 || b < y0 || b > y1) return false;
+    t_out = t;
+    return true;
+}
+// Side k of Shape::new_box (shape.rs:157-215): x0(F) x1 y0(F) y1 z0(F) z1.  A Rectangle reads its
+// (lower_left, upper_right) pairs in (p1, p2) order, which is (z, x) for Axis::Y (shape.rs:315-319), but
+// new_box fills the y sides with (x0, z0) / (x1, z1) (shape.rs:180-195): on those two sides the hit
+// point's z is tested against the box's x range and its x against the z range.  Reproduced as is.
+RT_HD void box_side(const rt_box& B, int k, uint32_t& axis, float& x0, float& y0, float& x1, float& y1, float& h) {
+    axis = (uint32_t)(k >> 1);
+    int p1, p2, oo; axis_perm(axis, p1, p2, oo);
+    if (axis == 1) { x0 = B.min[0]; y0 = B.min[2]; x1 = B.max[0]; y1 = B.max[2]; }
+    else { x0 = B.min[p1]; y0 = B.min[p2]; x1 = B.max[p1]; y1 = B.max[p2]; }
+    h = (k & 1) ? B.max[oo] : B.min[oo];
+}
+// Box = Vec<Shape>::intersect over the six sides with shrinking tmax (shape.rs:17-34):
+// the smallest accepted t wins and a later side wins an exact tie.
+RT_HD bool box_t(const rt_box& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        uint32_t axis; float x0, y0, x1, y1, h, t;
+        box_side(B, k, axis, x0, y0, x1, y1, h);
+        if (rect_t(axis, x0, y0, x1, y1, h, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
+    }
+    return any;
+}
+
+// Ray parameter of the innermost shape for a ray already in its frame.
+RT_HD bool geom_t(const SceneView& S, const rt_prim& P, V3 o, V3 d, float tmin, float tmax, float time, float& t, int& side) {
+    side = 0;
+    if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
+        double t64;
+        if (!sphere_t(S.spheres[P.geom_index], P.geom == RT_GEOM_MOVING_SPHERE, o, d, tmin, tmax, time, t64)) return false;
+        t = (float)t64;
+        return true;
+    }
+    if (P.geom == RT_GEOM_RECT) {
+        const rt_rect R = S.rects[P.geom_index];
+        return rect_t(R.axis, R.x0, R.y0, R.x1, R.y1, R.height, o, d, tmin, tmax, t);
+    }
+    return box_t(S.boxes[P.geom_index], o, d, tmin, tmax, t, side);
+}
+
+// Intersection::intersect reduced to the accepted ray parameter (plus the box
+// side).  ConstantMedium follows shape.rs:386-410 step by step.
+RT_HD bool prim_t(const SceneView& S, uint32_t prim, V3 o, V3 d, float tmin, float tmax, float time, const DrawKey& key, float& t, int& side) {
+    const rt_prim P = S.prims[prim];
+    to_local(S, P, o, d);
+    if (!(P.flags & RT_PRIM_MEDIUM)) return geom_t(S, P, o, d, tmin, tmax, time, t, side);
+    float t1, t2; int s_;
+    if (!geom_t(S, P, o, d, -RT_INF_F, RT_INF_F, time, t1, s_)) return false;
+    if (!geom_t(S, P, o, d, t1 + 0.001f, RT_INF_F, time, t2, s_)) return false;
+    t1 = fmaxf(t1, tmin);
+    t2 = fminf(t2, tmax);
+    if (t1 >= t2) return false;
+    t1 = fmaxf(t1, 0.0f);
+    float length = norm(d);
+    float inside = (t2 - t1) * length;
+    float hit_distance = -1.0f / P.density * logf(medium_variate(key, prim));
+    if (hit_distance > inside) return false;
+    t = t1 + hit_distance / length;
+    side = 0;
+    return true;
+}
+
+struct Hit {  // IntersectionPoint (shape.rs:539-550)
+    float t, u, v;
+    V3 point, normal, in_vec;
+    uint32_t prim;
+};
+
+// The rest of the IntersectionPoint for an accepted (prim, t, side): point,
+// normal, in_vec and surface coordinates, carried back out through the wrappers
+// (Rotated rotates point / normal / in_vec by +angle, shape.rs:378-383;
+// Translated adds the offset to the point, shape.rs:364-367).
+RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float time, float t, int side, Hit& h) {
+    const rt_prim P = S.prims[prim];
+    const V3 wd = d;
+    to_local(S, P, o, d);
+    V3 n, pt;
+    float u = 0.0f, v = 0.0f;
+    uint32_t back_from = P.xf_count;  // wrappers [0, back_from) are undone on the way out
+    if (P.flags & RT_PRIM_MEDIUM) {
+        pt = ray_at(o, d, t);
+        // the medium's hit lives in the frame of the ConstantMedium wrapper; undo the inner wrappers for the point
+        for (uint32_t k = P.xf_count; k > P.xf_outer; --k) {
+            const rt_xform X = S.xforms[P.xf_first + k - 1];
+            if (X.kind == RT_XF_TRANSLATE) pt = pt + v3(X.a, X.b, X.c); else pt = rotate_cs(pt, X.kind, X.a, X.b);
+        }
+        n = v3(1.0f, 0.0f, 0.0f);  // shape.rs:413
+        back_from = P.xf_outer;
+    } else if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
+        const rt_sphere sp = S.spheres[P.geom_index];
+        bool moving = P.geom == RT_GEOM_MOVING_SPHERE;
+        double t64 = (double)t;
+        sphere_root(sp, moving, o, d, time, t64);  // re-solve: the point and normal need the f64 root
+        D3 c = sphere_center(sp, moving, time);
+        D3 p = (t64 <= 0.0) ? d3(o) : d3(o) + d3(d) * t64;
+        D3 pc = p - c;
+        double inv_len = 1.0 / sqrt(dot(pc, pc));
+        n = v3(pc * inv_len);
+        D3 q = pc * (1.0 / sp.radius);  // shape.rs:275 divides by the signed radius
+        float phi = atan2f((float)q.z, (float)q.x);
+        float theta = atan2f((float)q.y, (float)sqrt(q.x * q.x + q.z * q.z));  // = asin(q.y) for unit q, well conditioned at the poles
+        u = 1.0f - (phi + RT_PI_F) / (2.0f * RT_PI_F);
+        v = (theta + RT_PI_F / 2.0f) / RT_PI_F;
+        pt = v3(p);
+    } else {
+        uint32_t axis; float x0, y0, x1, y1, hgt; bool flip_side = false;
+        if (P.geom == RT_GEOM_RECT) {
+            const rt_rect R = S.rects[P.geom_index];
+            axis = R.axis; x0 = R.x0; y0 = R.y0; x1 = R.x1; y1 = R.y1; hgt = R.height;
+        } else {
+            box_side(S.boxes[P.geom_index], side, axis, x0, y0, x1, y1, hgt);
+            flip_side = (side & 1) == 0;  // the x0 / y0 / z0 sides are Flipped (outward normals)
+        }
+        int p1, p2, oo; axis_perm(axis, p1, p2, oo);
+        pt = ray_at(o, d, t);
+        // The reference's f64 point lies on the plane to ~1e-13; fp32 would leave it up to an ulp of the
+        // coordinate away, enough for a grazing follow-up ray to hit the same plane again beyond tmin.
+        if (t > 0.0f) { if (oo == 0) pt.x = hgt; else if (oo == 1) pt.y = hgt; else pt.z = hgt; }
+        u = (comp(pt, p1) - x0) / (x1 - x0);
+        v = (comp(pt, p2) - y0) / (y1 - y0);
+        float s = flip_side ? -1.0f : 1.0f;
+        n = v3(oo == 0 ? s : 0.0f, oo == 1 ? s : 0.0f, oo == 2 ? s : 0.0f);
+    }
+    for (uint32_t k = back_from; k > 0; --k) {
+        const rt_xform X = S.xforms[P.xf_first + k - 1];
+        if (X.kind == RT_XF_TRANSLATE) pt = pt + v3(X.a, X.b, X.c);
+        else { pt = rotate_cs(pt, X.kind, X.a, X.b); n = rotate_cs(n, X.kind, X.a, X.b); }
+    }
+    if (P.flags & RT_PRIM_FLIP) n = -n;
+    h.t = t; h.u = u; h.v = v; h.point = pt; h.normal = n; h.in_vec = normed(wd); h.prim = prim;
+}
+
+// --------------------------------------------------------------- traversal
+struct Ray {
+    V3 o, d;
+    float time;
+};
+
+// BvhNode::scatter_ (lib.rs:228-257) as a stackless walk over the pre-order node array:
+// a node whose box the ray misses within (tmin, tmax) is skipped with its subtree, otherwise
+// the walk moves to the next node in pre-order (the left child); an accepted leaf hit lowers
+// tmax, and a later accepted hit replaces an earlier one.  Leaves are reached in the
+// reference's left-then-right order.  Node boxes are widened by the host, so the fp32 slab
+// test errs on the side of visiting.
+RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax, const DrawKey& key, float& best_t, uint32_t& best_prim, int& best_side) {
+    bool found = false;
+    const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+    uint32_t i = 0;
+    const uint32_t n = S.n_bvh_nodes;
+    while (i < n) {
+        const rt_bvh_node N = S.bvh[i];
+        float x0 = fmaf(N.min[0], inv.x, -oi.x), x1 = fmaf(N.max[0], inv.x, -oi.x);
+        float y0 = fmaf(N.min[1], inv.y, -oi.y), y1 = fmaf(N.max[1], inv.y, -oi.y);
+        float z0 = fmaf(N.min[2], inv.z, -oi.z), z1 = fmaf(N.max[2], inv.z, -oi.z);
+        float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+        float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+        if (!(tn <= tf)) { i = N.skip; continue; }
+        if (N.prim != RT_BVH_NONE) {
+            const uint32_t prim = N.prim & ~RT_BVH_EXACT;
+            bool enter = true;
+            if (N.prim & RT_BVH_EXACT) {
+                // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: true division of (bound - origin),
+                // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
+                float a0 = (N.min[0] - r.o.x) / r.d.x, a1 = (N.max[0] - r.o.x) / r.d.x;
+                float b0 = (N.min[1] - r.o.y) / r.d.y, b1 = (N.max[1] - r.o.y) / r.d.y;
+                float c0 = (N.min[2] - r.o.z) / r.d.z, c1 = (N.max[2] - r.o.z) / r.d.z;
+                float lo = tmin, hi = tmax;
+                lo = fmaxf(r.d.x < 0.0f ? a1 : a0, lo); hi = fminf(r.d.x < 0.0f ? a0 : a1, hi);
+                enter = !(hi <= lo);
+                lo = fmaxf(r.d.y < 0.0f ? b1 : b0, lo); hi = fminf(r.d.y < 0.0f ? b0 : b1, hi);
+                enter = enter && !(hi <= lo);
+                lo = fmaxf(r.d.z < 0.0f ? c1 : c0, lo); hi = fminf(r.d.z < 0.0f ? c0 : c1, hi);
+                enter = enter && !(hi <= lo);
+            }
+            float t; int side;
+            if (enter && prim_t(S, prim, r.o, r.d, tmin, tmax, r.time, key, t, side)) { tmax = t; best_t = t; best_prim = prim; best_side = side; found = true; }
+        }
+        ++i;
+    }
+    return found;
+}
+
+// ---------------------------------------------------------------- textures
+// noise 0.6.0 `Perlin::get` for [f64;3] points (third party, restated from the
+// crate's published algorithm; not verifiable offline): eight surflets
+// attn^4 * (d . grad), attn = 1 - |d|^2, scaled and clamped to [-1,1].
+RT_HD V3 perlin_grad3(uint32_t index) {
+    const float d = 0.70710678118654752f, e = 0.57735026918962576f;
+    uint32_t i = index & 31u;
+    if (i >= 24u) return v3((i & 1u) ? -e : e, (i & 2u) ? -e : e, (i & 4u) ? -e : e);
+    if (i >= 12u) i -= 12u;
+    float a = (i & 1u) ? -d : d, b = (i & 2u) ? -d : d;
+    if (i < 4u) return v3(a, b, 0.0f);
+    if (i < 8u) return v3(a, 0.0f, b);
+    return v3(0.0f, a, b);
+}
+RT_HD float perlin3(const uint8_t* perm, V3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+    float dx = p.x - fx, dy = p.y - fy, dz = p.z - fz;
+    float total = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
+        V3 dd = v3(dx - (float)cx, dy - (float)cy, dz - (float)cz);
+        float attn = 1.0f - dot(dd, dd);
+        if (attn > 0.0f) {
+            uint32_t hsh = perm[(uint32_t)(ix + cx) & 255u];
+            hsh = perm[hsh ^ ((uint32_t)(iy + cy) & 255u)];
+            hsh = perm[hsh ^ ((uint32_t)(iz + cz) & 255u)];
+            float a2 = attn * attn;
+            total = fmaf(a2 * a2, dot(dd, perlin_grad3(hsh)), total);
+        }
+    }
+    float r = total * 3.8898553255531074f;
+    return fminf(fmaxf(r, -1.0f), 1.0f);
+}
+
+// Texture::color_at (textures.rs:46-78).
+RT_HD V3 texture_color(const SceneView& S, uint32_t tex, float u, float v, V3 p) {
+    rt_texture T = S.textures[tex];
+    for (uint32_t depth = 0; T.kind == RT_TEX_CHECKERED && depth < RT_MAX_TEXTURE_NESTING; ++depth) {
+        bool odd = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z) < 0.0f;
+        T = S.textures[odd ? T.odd : T.even];
+    }
+    if (T.kind == RT_TEX_NOISE) {
+        float n = perlin3(S.perm + 256u * T.resource, v3(p.x * T.scale, p.y * T.scale, p.z * T.scale));
+        return v3(n, n, n);  // may be negative: the reference does not clamp
+    }
+    if (T.kind == RT_TEX_IMAGE) {
+        const rt_image I = S.images[T.resource];
+        float uu = fminf(fmaxf(u, 0.0f), 1.0f);
+        float vv = 1.0f - fminf(fmaxf(v, 0.0f), 1.0f);
+        uint32_t i = (uint32_t)(uu * (float)I.width), j = (uint32_t)(vv * (float)I.height);
+        i = i < I.width - 1 ? i : I.width - 1;
+        j = j < I.height - 1 ? j : I.height - 1;
+        const uint8_t* px = S.texels + I.texel_offset + 3ull * ((uint64_t)j * I.width + i);
+        return v3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    }
+    return v3(T.color[0], T.color[1], T.color[2]);
+}
+
+// --------------------------------------------------------------- materials
+// OnUnitSphere (geometry.rs:372-382): r = 1 - z^2 without the square root, then normalised.
+// The sampler piles probability up at the poles z = +-1, where r -> 0; the normalisation runs in
+// f64 (on fp32 cos/sin) so that the z component keeps its distance from +-1, which Lambertian
+// scattering off a z-facing surface depends on.
+RT_HD D3 random_unit_vector_d(float u_phi, float u_z) {
+    float phi = (2.0f * RT_PI_F) * u_phi;
+    double z = 2.0 * (double)u_z - 1.0;
+    double r = 1.0 - z * z;
+    double x = r * (double)cosf(phi), y = r * (double)sinf(phi);
+    double inv = 1.0 / sqrt(x * x + y * y + z * z);
+    return d3(x * inv, y * inv, z * inv);
+}
+RT_HD V3 random_unit_vector(float u_phi, float u_z) { return v3(random_unit_vector_d(u_phi, u_z)); }
+RT_HD V3 reflect(V3 v, V3 n) { return normed(v - n * (2.0f * dot(v, n))); }  // materials.rs:132
+RT_HD V3 refract(V3 v, V3 n, float eta) {                                      // materials.rs:136
+    float cos_theta = -dot(v, n);
+    V3 out_par = (v + n * cos_theta) * eta;
+    // the reference's f64 argument cannot go negative here in practice (refract is only called below the
+    // critical angle); fp32 rounding can, hence the clamp
+    V3 out_perp = n * -(sqrtf(fmaxf(1.0f - dot(out_par, out_par), 0.0f)));
+    return out_par + out_perp;
+}
+RT_HD float schlick(float cosine, float ri) {  // materials.rs:143
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float m = 1.0f - cosine, m2 = m * m;
+    return r0 + (1.0f - r0) * (m2 * m2 * m);
+}
+
+struct Scatter { bool scattered; V3 color; V3 o, d; };  // RayHit (lib.rs:300-306)
+
+// Material::scatter (materials.rs:28-114) with the draws of stream 0 of the segment.
+RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& key) {
+    const rt_material M = S.materials[S.prims[h.prim].material];
+    const U4 rnd = philox4x32_10(key.pixel, key.sample, key.bounce, 0u, key.k0, key.k1);
+    Scatter out;
+    out.o = h.point;
+    out.d = v3(0.0f, 0.0f, 0.0f);
+    if (M.kind == RT_MAT_LAMBERTIAN) {
+        // direction = random_unit_vector + normal; attenuation = tex * max(cos/pi, 0) * pi / cos with
+        // cos = normal . normed(direction) (materials.rs:31-44).  The sum cancels when the random vector is
+        // nearly opposite to the normal, so it is formed in f64 like the reference's.
+        D3 nd = d3(h.normal);
+        D3 dir = random_unit_vector_d(u01(rnd.x), u01(rnd.y)) + nd;
+        double cosine = dot(nd, dir) / sqrt(dot(dir, dir));
+        double pdf = fmax(cosine / RT_PI_D, 0.0);
+        float w = (float)((pdf * RT_PI_D) / cosine);
+        V3 tex = texture_color(S, M.texture, h.u, h.v, h.point);
+        out.color = tex * w;
+        out.scattered = true; out.d = v3(dir);
+    } else if (M.kind == RT_MAT_METAL) {
+        V3 refl = reflect(h.in_vec, h.normal);
+        V3 s = refl + random_unit_vector(u01(rnd.x), u01(rnd.y)) * M.param;  // fuzz is not clamped
+        if (dot(s, h.normal) >= 0.0f) { out.scattered = true; out.color = v3(M.albedo[0], M.albedo[1], M.albedo[2]); out.d = s; }
+        else { out.scattered = false; out.color = v3(0.0f, 0.0f, 0.0f); }
+    } else if (M.kind == RT_MAT_DIELECTRIC) {
+        bool front = dot(h.in_vec, h.normal) < 0.0f;  // shape.rs:554
+        float eta = front ? 1.0f / M.param : M.param;
+        V3 in_unit = normed(h.in_vec);
+        float cos_theta = -fminf(dot(in_unit, h.normal), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        V3 dir;
+        if (eta * sin_theta > 1.0f || u01(rnd.z) < schlick(cos_theta, eta)) dir = reflect(in_unit, h.normal);
+        else dir = refract(in_unit, h.normal, eta);
+        out.scattered = true; out.color = v3(M.albedo[0], M.albedo[1], M.albedo[2]); out.d = dir;
+    } else if (M.kind == RT_MAT_DIFFUSE_LIGHT) {
+        out.scattered = false; out.color = texture_color(S, M.texture, h.u, h.v, h.point);
+    } else {  // Isotropic
+        out.scattered = true; out.d = random_unit_vector(u01(rnd.x), u01(rnd.y));
+        out.color = texture_color(S, M.texture, h.u, h.v, h.point);
+    }
+    return out;
+}
+
+// One step of ray_color (lib.rs:89-101) for a ray whose closest hit is known.
+// Returns true when the path continues (r and thr updated); otherwise `value` is the
+// sample's final radiance.
+RT_HD bool shade_step(const SceneView& S, Ray& r, V3& thr, const DrawKey& key, bool hit, float t, uint32_t prim, int side, bool last_bounce, V3& value) {
+    if (!hit) { value = thr * v3(S.background[0], S.background[1], S.background[2]); return false; }  // lib.rs:91
+    Hit h;
+    prim_surface(S, prim, r.o, r.d, r.time, t, side, h);
+    Scatter sc = material_scatter(S, h, key);
+    if (!sc.scattered) { value = thr * sc.color; return false; }  // lib.rs:92
+    thr = thr * sc.color;
+    r.o = sc.o; r.d = sc.d;
+    // lib.rs:103: a path that is still alive after max_reflections segments is black.  A path whose
+    // throughput is exactly zero can only ever contribute zero, so it ends here as well.
+    if (last_bounce || (thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f)) { value = v3(0.0f, 0.0f, 0.0f); return false; }
+    return true;
+}
+
+// ------------------------------------------------------------------ camera
+// pixel() / Camera::ray / random_time (lib.rs:55-60, :389-401) in f64, rounded
+// to fp32 at the end.  (i, j) = (column, row counted from the bottom).
+RT_HD Ray camera_ray(const rt_camera& C, uint32_t i, uint32_t j, uint32_t width, uint32_t height, uint32_t sample, uint32_t k0, uint32_t k1) {
+    const uint32_t pixel = j * width + i;
+    const U4 r0 = philox4x32_10(pixel, sample, RT_TAG_CAMERA, 0u, k0, k1);
+    const double s = ((double)i + (double)u01(r0.x)) / (double)(width - 1);
+    const double t = ((double)j + (double)u01(r0.y)) / (double)(height - 1);
+    double dx, dy;
+    for (uint32_t round = 1;; ++round) {  // InsideUnitDisc (geometry.rs:397-408), two candidates per Philox block
+        const U4 q = philox4x32_10(pixel, sample, RT_TAG_CAMERA, round, k0, k1);
+        dx = -1.0 + 2.0 * (double)u01(q.x); dy = -1.0 + 2.0 * (double)u01(q.y);
+        if (!(sqrt(dx * dx + dy * dy) >= 1.0)) break;
+        dx = -1.0 + 2.0 * (double)u01(q.z); dy = -1.0 + 2.0 * (double)u01(q.w);
+        if (!(sqrt(dx * dx + dy * dy) >= 1.0)) break;
+    }
+    dx *= C.lens_radius; dy *= C.lens_radius;
+    D3 offset = d3(C.u) * dx + d3(C.v) * dy;
+    D3 org = d3(C.origin) + offset;
+    D3 dir = (d3(C.lower_left_corner) + d3(C.horizontal) * s + d3(C.vertical) * t) - org;
+    Ray r;
+    r.o = v3(org); r.d = v3(dir);
+    r.time = (float)(C.shutter_open + (C.shutter_close - C.shutter_open) * (double)u01(r0.z));
+    return r;
+}
+
+// lib.rs:68-72: x.max(0).min(1).sqrt() * 255.999 as u8 (saturating, NaN -> 0).
+RT_HD uint8_t quantise(double x) {
+    double y = sqrt(fmin(fmax(x, 0.0), 1.0)) * 255.999;
+    if (!(y > 0.0)) return 0;
+    if (y >= 255.0) return 255;
+    return (uint8_t)y;
+}
+
+}  // namespace rt
+#endif

@@ -1,0 +1,693 @@
+// rt_hip.hip -- HIP kernels for gfx950 and the C ABI of include/rt_abi.h.
+//
+// Wavefront path tracer.  One pass traces `n_paths = owned_pixels * S` camera
+// paths (S samples of every pixel this rank owns):
+//
+//   k_raygen    one thread per path: pixel() / Camera::ray (lib.rs:55-60, :389)
+//   per bounce  k_traverse  closest hit through the BVH  (lib.rs:228-257 + shape.rs:248-426)
+//               k_shade     Material::scatter + Texture::color_at (materials.rs:28, textures.rs:46),
+//                           throughput update of ray_color (lib.rs:89-101), and compaction of the
+//                           surviving rays into the next queue (wave ballot + per-block prefix,
+//                           one atomic per block)
+//   k_tail      once the queue is short: every remaining path runs to its end in one launch
+//   k_resolve   per-pixel sum of the pass's sample values in sample order (lib.rs:65)
+//   k_finalize  mean radiance -> full-frame f64 buffer (zeros for pixels of other ranks)
+//
+// Every random draw is Philox4x32-10 keyed on (pixel, sample, bounce, stream), each
+// sample value is written to a slot of its own and summed in sample order, so the image
+// does not depend on queue order, pass size, tile split or GPU count.
+//
+// HBM layout (per scene handle, sized for the largest pass): two ray queues of
+// {float4 o.xyz|d.x, float4 d.yz|time|path, float4 throughput}, one hit queue of
+// {t, prim|side} and one float4 sample value per path; per-pixel f64 sums.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_core.h"
+
+using namespace rt;
+
+#define RT_BS 256
+#define RT_HIT_NONE 0xFFFFFFFFu
+
+// ------------------------------------------------------------------ device
+struct RayQueue {
+    float4* od0;  // o.x o.y o.z d.x
+    float4* od1;  // d.y d.z time path(bits)
+    float4* thr;  // throughput rgb, unused
+};
+
+struct PassParams {
+    rt_camera cam;
+    uint32_t width, height;
+    uint32_t n_owned;      // pixels owned by this rank
+    uint32_t n_paths;      // n_owned * samples in this pass
+    uint32_t sample_base;  // first sample index of the pass
+    uint32_t k0, k1;       // seed
+    uint32_t max_depth;
+    const uint32_t* owned; // global pixel id (j * width + i) of every owned pixel
+};
+
+__device__ __forceinline__ DrawKey make_key(const PassParams& P, uint32_t path, uint32_t bounce) {
+    DrawKey k;
+    k.k0 = P.k0; k.k1 = P.k1;
+    k.pixel = P.owned[path % P.n_owned];
+    k.sample = P.sample_base + path / P.n_owned;
+    k.bounce = bounce;
+    k.medium_u = -1.0f;
+    return k;
+}
+
+__global__ void __launch_bounds__(RT_BS) k_raygen(PassParams P, RayQueue q, uint32_t* counts, uint32_t n_counts) {
+    uint32_t p = blockIdx.x * RT_BS + threadIdx.x;
+    if (p == 0) {
+        counts[0] = P.n_paths;
+        for (uint32_t i = 1; i < n_counts; ++i) counts[i] = 0;
+    }
+    if (p >= P.n_paths) return;
+    uint32_t pixel = P.owned[p % P.n_owned];
+    uint32_t sample = P.sample_base + p / P.n_owned;
+    Ray r = camera_ray(P.cam, pixel % P.width, pixel / P.width, P.width, P.height, sample, P.k0, P.k1);
+    q.od0[p] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+    q.od1[p] = make_float4(r.d.y, r.d.z, r.time, __uint_as_float(p));
+    q.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+}
+
+__global__ void __launch_bounds__(RT_BS) k_traverse(SceneView S, PassParams P, RayQueue q, const uint32_t* count_ptr, uint2* hits, uint32_t bounce) {
+    const uint32_t count = *count_ptr;
+    for (uint32_t i = blockIdx.x * RT_BS + threadIdx.x; i < count; i += gridDim.x * RT_BS) {
+        float4 a = q.od0[i], b = q.od1[i];
+        Ray r; r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
+        DrawKey key = make_key(P, __float_as_uint(b.w), bounce);
+        float t = 0.0f; uint32_t prim = 0; int side = 0;
+        bool hit = closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);  // lib.rs:90: (0.001, inf)
+        hits[i] = make_uint2(__float_as_uint(t), hit ? (prim | ((uint32_t)side << 29)) : RT_HIT_NONE);
+    }
+}
+
+__global__ void __launch_bounds__(RT_BS) k_shade(SceneView S, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+                                                 uint32_t* next_count, float4* values, uint32_t bounce) {
+    __shared__ uint32_t wave_cnt[RT_BS / 64];
+    __shared__ uint32_t block_base;
+    const uint32_t count = *count_ptr;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * RT_BS; base < count; base += gridDim.x * RT_BS) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        Ray r; V3 thr; uint32_t path = 0;
+        if (i < count) {
+            float4 a = qin.od0[i], b = qin.od1[i], c = qin.thr[i];
+            uint2 hh = hits[i];
+            r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
+            path = __float_as_uint(b.w);
+            thr = v3(c.x, c.y, c.z);
+            DrawKey key = make_key(P, path, bounce);
+            V3 value;
+            bool hit = hh.y != RT_HIT_NONE;
+            alive = shade_step(S, r, thr, key, hit, __uint_as_float(hh.x), hh.y & 0x1FFFFFFFu, (int)(hh.y >> 29), bounce + 1 >= P.max_depth, value);
+            if (!alive) values[path] = make_float4(value.x, value.y, value.z, 0.0f);
+        }
+        // compaction: ballot + lane prefix inside the wave, one atomic per block
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < RT_BS / 64; ++w) { uint32_t c = wave_cnt[w]; wave_cnt[w] = total; total += c; }
+            block_base = total ? atomicAdd(next_count, total) : 0u;
+        }
+        __syncthreads();
+        if (alive) {
+            const uint32_t slot = block_base + wave_cnt[wave] + prefix;
+            qout.od0[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+            qout.od1[slot] = make_float4(r.d.y, r.d.z, r.time, __uint_as_float(path));
+            qout.thr[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+        }
+        __syncthreads();
+    }
+}
+
+// Every ray left in the queue runs the remaining iterations of ray_color in one launch.
+__global__ void __launch_bounds__(RT_BS) k_tail(SceneView S, PassParams P, RayQueue q, const uint32_t* count_ptr, float4* values, uint32_t* segment_counter,
+                                                uint32_t first_bounce) {
+    const uint32_t count = *count_ptr;
+    uint32_t segments = 0;
+    for (uint32_t i = blockIdx.x * RT_BS + threadIdx.x; i < count; i += gridDim.x * RT_BS) {
+        float4 a = q.od0[i], b = q.od1[i], c = q.thr[i];
+        Ray r; r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
+        const uint32_t path = __float_as_uint(b.w);
+        V3 thr = v3(c.x, c.y, c.z);
+        V3 value = v3(0.0f, 0.0f, 0.0f);
+        DrawKey key = make_key(P, path, first_bounce);
+        for (uint32_t bounce = first_bounce; bounce < P.max_depth; ++bounce) {
+            key.bounce = bounce;
+            ++segments;
+            float t = 0.0f; uint32_t prim = 0; int side = 0;
+            bool hit = closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);
+            if (!shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value)) break;
+        }
+        values[path] = make_float4(value.x, value.y, value.z, 0.0f);
+    }
+    // segments traced by this launch (profiling only): one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) segments += __shfl_down(segments, off);
+    if ((threadIdx.x & 63u) == 0 && segments) atomicAdd(segment_counter, segments);
+}
+
+// accum[pixel] += value(sample s) for s ascending: the f64 sum of lib.rs:65 in sample order.
+__global__ void __launch_bounds__(RT_BS) k_resolve(const float4* values, double* accum, uint32_t n_owned, uint32_t n_samples) {
+    uint32_t pl = blockIdx.x * RT_BS + threadIdx.x;
+    if (pl >= n_owned) return;
+    double r = accum[3 * (size_t)pl], g = accum[3 * (size_t)pl + 1], b = accum[3 * (size_t)pl + 2];
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        float4 v = values[(size_t)s * n_owned + pl];
+        r += (double)v.x; g += (double)v.y; b += (double)v.z;
+    }
+    accum[3 * (size_t)pl] = r; accum[3 * (size_t)pl + 1] = g; accum[3 * (size_t)pl + 2] = b;
+}
+
+// mean = sum / spp (lib.rs:66) scattered to the output frame: row 0 = top = j = height-1 (lib.rs:21-23).
+__global__ void __launch_bounds__(RT_BS) k_finalize(const double* accum, const uint32_t* owned, uint32_t n_owned, uint32_t width, uint32_t height,
+                                                    double spp, double* mean_out) {
+    uint32_t pl = blockIdx.x * RT_BS + threadIdx.x;
+    if (pl >= n_owned) return;
+    uint32_t pixel = owned[pl], i = pixel % width, j = pixel / width;
+    size_t o = 3 * ((size_t)(height - 1 - j) * width + i);
+    mean_out[o] = accum[3 * (size_t)pl] / spp;
+    mean_out[o + 1] = accum[3 * (size_t)pl + 1] / spp;
+    mean_out[o + 2] = accum[3 * (size_t)pl + 2] / spp;
+}
+
+__global__ void __launch_bounds__(RT_BS) k_quantise(const double* mean, uint64_t n, uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * RT_BS + threadIdx.x;
+    if (i < n) out[i] = quantise(mean[i]);
+}
+
+__global__ void __launch_bounds__(RT_BS) k_intersect_batch(SceneView S, int64_t scope, const rt_ray* rays, uint64_t n, float tmin, float tmax,
+                                                           uint32_t k0, uint32_t k1, const float* medium_u, rt_hit* out) {
+    uint64_t i = (uint64_t)blockIdx.x * RT_BS + threadIdx.x;
+    if (i >= n) return;
+    rt_ray in = rays[i];
+    Ray r; r.o = v3(in.origin[0], in.origin[1], in.origin[2]); r.d = v3(in.direction[0], in.direction[1], in.direction[2]); r.time = in.time;
+    DrawKey key; key.k0 = k0; key.k1 = k1; key.pixel = (uint32_t)i; key.sample = 0; key.bounce = 0;
+    key.medium_u = medium_u ? medium_u[i] : -1.0f;
+    float t = 0.0f; uint32_t prim = 0; int side = 0;
+    bool hit;
+    if (scope < 0) hit = closest_hit(S, r, tmin, tmax, key, t, prim, side);
+    else { prim = (uint32_t)scope; hit = prim_t(S, prim, r.o, r.d, tmin, tmax, r.time, key, t, side); }
+    rt_hit o;
+    memset(&o, 0, sizeof(o));
+    if (hit) {
+        Hit h;
+        prim_surface(S, prim, r.o, r.d, r.time, t, side, h);
+        o.hit = 1; o.prim = prim; o.t = h.t; o.u = h.u; o.v = h.v;
+        o.point[0] = h.point.x; o.point[1] = h.point.y; o.point[2] = h.point.z;
+        o.normal[0] = h.normal.x; o.normal[1] = h.normal.y; o.normal[2] = h.normal.z;
+        o.in_vec[0] = h.in_vec.x; o.in_vec[1] = h.in_vec.y; o.in_vec[2] = h.in_vec.z;
+    }
+    out[i] = o;
+}
+
+__global__ void __launch_bounds__(RT_BS) k_camera_rays(rt_camera cam, uint32_t width, uint32_t height, uint32_t k0, uint32_t k1, uint64_t n,
+                                                       const uint32_t* px_i, const uint32_t* px_j, const uint32_t* sample, rt_ray* out) {
+    uint64_t k = (uint64_t)blockIdx.x * RT_BS + threadIdx.x;
+    if (k >= n) return;
+    Ray r = camera_ray(cam, px_i[k], px_j[k], width, height, sample[k], k0, k1);
+    rt_ray o;
+    o.origin[0] = r.o.x; o.origin[1] = r.o.y; o.origin[2] = r.o.z;
+    o.direction[0] = r.d.x; o.direction[1] = r.d.y; o.direction[2] = r.d.z;
+    o.time = r.time;
+    out[k] = o;
+}
+
+// -------------------------------------------------------------------- host
+static thread_local std::string g_err;
+static rt_status fail(rt_status s, const std::string& m) { g_err = m; return s; }
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,                         \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                    \
+        }                                                                                                      \
+    } while (0)
+
+struct rt_scene {
+    int device = 0;
+    SceneView view{};
+    std::vector<void*> allocs;
+    hipStream_t own_stream = nullptr;
+    // workspace
+    uint64_t ws_paths = 0, ws_pixels = 0;
+    RayQueue q[2]{};
+    uint2* hits = nullptr;
+    float4* values = nullptr;
+    double* accum = nullptr;
+    uint32_t* owned = nullptr;
+    uint32_t* counts = nullptr;
+    uint32_t n_counts = 0;
+    uint32_t* h_counts = nullptr;  // pinned
+    std::vector<void*> ws_allocs;
+    // profile
+    rt_profile prof{};
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> events;
+    std::vector<hipEvent_t> event_pool;
+};
+
+template <class T>
+static rt_status upload(rt_scene* sc, const T* src, size_t n, const T** dst) {
+    *dst = nullptr;
+    if (n == 0) return RT_OK;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, n * sizeof(T)));
+    sc->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T*)d;
+    return RT_OK;
+}
+
+static rt_status validate_desc(const rt_scene_desc* D) {
+    if (!D) return fail(RT_ERR_INVALID_ARGUMENT, "scene description is null");
+    if (D->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "abi_version mismatch");
+    if (D->n_prims == 0) return fail(RT_ERR_EMPTY_SCENE, "a scene needs at least one object (Scene::new asserts this)");
+    if (D->n_prims >= (1u << 29)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
+    if (!D->prims || !D->materials || D->n_materials == 0) return fail(RT_ERR_INVALID_ARGUMENT, "prims / materials missing");
+    if ((D->n_spheres && !D->spheres) || (D->n_rects && !D->rects) || (D->n_boxes && !D->boxes) || (D->n_xforms && !D->xforms) ||
+        (D->n_textures && !D->textures) || (D->n_images && !D->images) || (D->n_perm_tables && !D->perm_tables) || (D->n_bvh_nodes && !D->bvh))
+        return fail(RT_ERR_INVALID_ARGUMENT, "an array with a non-zero count is null");
+    for (uint32_t i = 0; i < D->n_textures; ++i) {
+        const rt_texture& T = D->textures[i];
+        if (T.kind > RT_TEX_IMAGE) return fail(RT_ERR_INVALID_ARGUMENT, "texture kind out of range");
+        if (T.kind == RT_TEX_CHECKERED && (T.odd >= D->n_textures || T.even >= D->n_textures)) return fail(RT_ERR_INVALID_ARGUMENT, "checker child out of range");
+        if (T.kind == RT_TEX_NOISE && T.resource >= D->n_perm_tables) return fail(RT_ERR_INVALID_ARGUMENT, "noise permutation table out of range");
+        if (T.kind == RT_TEX_IMAGE) {
+            if (T.resource >= D->n_images) return fail(RT_ERR_INVALID_ARGUMENT, "image index out of range");
+            const rt_image& I = D->images[T.resource];
+            if (I.width == 0 || I.height == 0 || !D->texels || I.texel_offset + 3ull * I.width * I.height > D->texel_bytes)
+                return fail(RT_ERR_INVALID_ARGUMENT, "image texels out of range");
+        }
+    }
+    // checker nesting: children must resolve to a leaf texture within RT_MAX_TEXTURE_NESTING levels on every branch
+    for (uint32_t i = 0; i < D->n_textures; ++i) {
+        std::vector<std::pair<uint32_t, uint32_t>> todo{{i, 0}};
+        size_t visited = 0;
+        while (!todo.empty()) {
+            auto [t, depth] = todo.back(); todo.pop_back();
+            if (++visited > 4096) return fail(RT_ERR_UNSUPPORTED, "checker texture tree too large");
+            if (D->textures[t].kind != RT_TEX_CHECKERED) continue;
+            if (depth >= RT_MAX_TEXTURE_NESTING) return fail(RT_ERR_UNSUPPORTED, "checker textures nested too deeply (or cyclic)");
+            todo.push_back({D->textures[t].odd, depth + 1}); todo.push_back({D->textures[t].even, depth + 1});
+        }
+    }
+    for (uint32_t i = 0; i < D->n_materials; ++i) {
+        const rt_material& M = D->materials[i];
+        if (M.kind > RT_MAT_ISOTROPIC) return fail(RT_ERR_INVALID_ARGUMENT, "material kind out of range");
+        bool textured = M.kind == RT_MAT_LAMBERTIAN || M.kind == RT_MAT_DIFFUSE_LIGHT || M.kind == RT_MAT_ISOTROPIC;
+        if (textured && M.texture >= D->n_textures) return fail(RT_ERR_INVALID_ARGUMENT, "material texture out of range");
+    }
+    for (uint32_t i = 0; i < D->n_prims; ++i) {
+        const rt_prim& P = D->prims[i];
+        uint32_t lim = P.geom <= RT_GEOM_MOVING_SPHERE ? D->n_spheres : P.geom == RT_GEOM_RECT ? D->n_rects : P.geom == RT_GEOM_BOX ? D->n_boxes : 0;
+        if (P.geom > RT_GEOM_BOX || P.geom_index >= lim) return fail(RT_ERR_INVALID_ARGUMENT, "primitive geometry out of range");
+        if (P.material >= D->n_materials) return fail(RT_ERR_INVALID_ARGUMENT, "primitive material out of range");
+        if (P.xf_count > RT_MAX_XFORMS_PER_PRIM) return fail(RT_ERR_UNSUPPORTED, "too many nested Translated/Rotated wrappers on one shape");
+        if ((uint64_t)P.xf_first + P.xf_count > D->n_xforms) return fail(RT_ERR_INVALID_ARGUMENT, "primitive transform range out of bounds");
+        if (P.xf_outer > P.xf_count) return fail(RT_ERR_INVALID_ARGUMENT, "xf_outer exceeds xf_count");
+        if (P.geom == RT_GEOM_RECT && D->rects[P.geom_index].axis > 2) return fail(RT_ERR_INVALID_ARGUMENT, "rectangle axis out of range");
+    }
+    for (uint32_t i = 0; i < D->n_xforms; ++i)
+        if (D->xforms[i].kind > RT_XF_ROTATE_Z) return fail(RT_ERR_INVALID_ARGUMENT, "transform kind out of range");
+    // BVH: pre-order with skip links.  skip > index makes every walk terminate; the nesting check makes the
+    // array a tree; every non-inert primitive sits in exactly one leaf.
+    std::vector<uint8_t> seen_prim(D->n_prims, 0);
+    {
+        std::vector<uint32_t> open_ends;  // skip values of the inner nodes we are inside of
+        for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) {
+            const rt_bvh_node& N = D->bvh[i];
+            while (!open_ends.empty() && open_ends.back() == i) open_ends.pop_back();
+            if (N.skip <= i || N.skip > D->n_bvh_nodes) return fail(RT_ERR_INVALID_ARGUMENT, "BVH skip link does not move forward");
+            if (!open_ends.empty() && N.skip > open_ends.back()) return fail(RT_ERR_INVALID_ARGUMENT, "BVH subtree crosses its parent's end");
+            if (N.prim != RT_BVH_NONE) {
+                if (N.skip != i + 1) return fail(RT_ERR_INVALID_ARGUMENT, "BVH leaf with a subtree");
+                const uint32_t pr = N.prim & ~RT_BVH_EXACT;
+                if (pr >= D->n_prims || seen_prim[pr]) return fail(RT_ERR_INVALID_ARGUMENT, "BVH leaf primitive out of range or repeated");
+                seen_prim[pr] = 1;
+            } else {
+                if (N.skip == i + 1) return fail(RT_ERR_INVALID_ARGUMENT, "BVH inner node without children");
+                open_ends.push_back(N.skip);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < D->n_prims; ++i)
+        if (!seen_prim[i] && !(D->prims[i].flags & RT_PRIM_INERT)) return fail(RT_ERR_INVALID_ARGUMENT, "a primitive is missing from the BVH");
+    return RT_OK;
+}
+
+static void free_workspace(rt_scene* sc) {
+    for (void* p : sc->ws_allocs) (void)hipFree(p);
+    sc->ws_allocs.clear();
+    if (sc->h_counts) { (void)hipHostFree(sc->h_counts); sc->h_counts = nullptr; }
+    sc->ws_paths = sc->ws_pixels = 0; sc->n_counts = 0;
+}
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+const char* rt_last_error(void) { return g_err.c_str(); }
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    free_workspace(sc);
+    for (void* p : sc->allocs) (void)hipFree(p);
+    for (auto& e : sc->event_pool) (void)hipEventDestroy(e);
+    if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
+    delete sc;
+}
+
+rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    rt_status st = validate_desc(D);
+    if (st != RT_OK) return st;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is available; this library has no CPU path");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= ndev) return fail(RT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    rt_scene* sc = new rt_scene();
+    sc->device = device;
+    SceneView& V = sc->view;
+#define UP(field, src, n) do { st = upload(sc, src, (size_t)(n), &V.field); if (st != RT_OK) { rt_scene_destroy(sc); return st; } } while (0)
+    UP(prims, D->prims, D->n_prims);
+    UP(spheres, D->spheres, D->n_spheres);
+    UP(rects, D->rects, D->n_rects);
+    UP(boxes, D->boxes, D->n_boxes);
+    UP(xforms, D->xforms, D->n_xforms);
+    UP(materials, D->materials, D->n_materials);
+    UP(textures, D->textures, D->n_textures);
+    UP(images, D->images, D->n_images);
+    UP(texels, D->texels, D->texel_bytes);
+    UP(perm, D->perm_tables, 256u * (size_t)D->n_perm_tables);
+    UP(bvh, D->bvh, D->n_bvh_nodes);
+#undef UP
+    V.n_prims = D->n_prims; V.n_bvh_nodes = D->n_bvh_nodes;
+    for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
+    hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    *out = sc;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+static rt_status ensure_workspace(rt_scene* sc, uint64_t n_paths, uint64_t n_pixels, uint32_t n_counts) {
+    if (n_paths <= sc->ws_paths && n_pixels <= sc->ws_pixels && n_counts <= sc->n_counts) return RT_OK;
+    free_workspace(sc);
+    n_paths = std::max<uint64_t>(n_paths, 1); n_pixels = std::max<uint64_t>(n_pixels, 1);
+    auto alloc = [&](void** p, size_t bytes) -> rt_status {
+        HIP_TRY(hipMalloc(p, bytes));
+        sc->ws_allocs.push_back(*p);
+        return RT_OK;
+    };
+    rt_status st;
+    for (int k = 0; k < 2; ++k) {
+        if ((st = alloc((void**)&sc->q[k].od0, n_paths * sizeof(float4))) != RT_OK) return st;
+        if ((st = alloc((void**)&sc->q[k].od1, n_paths * sizeof(float4))) != RT_OK) return st;
+        if ((st = alloc((void**)&sc->q[k].thr, n_paths * sizeof(float4))) != RT_OK) return st;
+    }
+    if ((st = alloc((void**)&sc->hits, n_paths * sizeof(uint2))) != RT_OK) return st;
+    if ((st = alloc((void**)&sc->values, n_paths * sizeof(float4))) != RT_OK) return st;
+    if ((st = alloc((void**)&sc->accum, n_pixels * 3 * sizeof(double))) != RT_OK) return st;
+    if ((st = alloc((void**)&sc->owned, n_pixels * sizeof(uint32_t))) != RT_OK) return st;
+    if ((st = alloc((void**)&sc->counts, n_counts * sizeof(uint32_t))) != RT_OK) return st;
+    HIP_TRY(hipHostMalloc((void**)&sc->h_counts, n_counts * sizeof(uint32_t), hipHostMallocDefault));
+    sc->ws_paths = n_paths; sc->ws_pixels = n_pixels; sc->n_counts = n_counts;
+    return RT_OK;
+}
+
+namespace {
+struct Launcher {
+    rt_scene* sc; hipStream_t stream; bool profile;
+    rt_status begin(int kind, hipEvent_t* stop_out) {
+        *stop_out = nullptr;
+        if (!profile) return RT_OK;
+        hipEvent_t ev[2];
+        for (int k = 0; k < 2; ++k) {
+            if (!sc->event_pool.empty()) { ev[k] = sc->event_pool.back(); sc->event_pool.pop_back(); }
+            else HIP_TRY(hipEventCreate(&ev[k]));
+        }
+        HIP_TRY(hipEventRecord(ev[0], stream));
+        sc->events.push_back({kind, {ev[0], ev[1]}});
+        *stop_out = ev[1];
+        return RT_OK;
+    }
+    rt_status end(hipEvent_t stop) {
+        HIP_TRY(hipGetLastError());
+        if (stop) HIP_TRY(hipEventRecord(stop, stream));
+        return RT_OK;
+    }
+};
+}  // namespace
+
+static rt_status collect_profile(rt_scene* sc) {
+    for (auto& e : sc->events) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.second.first, e.second.second));
+        sc->prof.kernel_ms[e.first] += ms;
+        sc->prof.kernel_launches[e.first] += 1;
+        sc->event_pool.push_back(e.second.first); sc->event_pool.push_back(e.second.second);
+    }
+    sc->events.clear();
+    return RT_OK;
+}
+
+static rt_status validate_render(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro) {
+    if (!sc || !cam || !io || !ro) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (io->width < 2 || io->height < 2) return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be at least 2 (pixel() divides by width-1 and height-1)");
+    if ((uint64_t)io->width * io->height >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "image too large");
+    if (io->samples_per_pixel == 0 || io->samples_per_pixel >= (1ull << 32)) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be in [1, 2^32)");
+    if (io->max_reflections >= (1ull << 31)) return fail(RT_ERR_INVALID_ARGUMENT, "max_reflections too large");
+    if (!(cam->shutter_open < cam->shutter_close)) return fail(RT_ERR_INVALID_ARGUMENT, "shutter_open must be below shutter_close (gen_range panics otherwise)");
+    if (ro->world_size == 0 || ro->rank >= ro->world_size) return fail(RT_ERR_INVALID_ARGUMENT, "rank / world_size invalid");
+    return RT_OK;
+}
+
+// Renders this rank's pixels into d_mean_out (full frame of doubles on the device).
+static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out, bool sync_at_end) {
+    rt_status st = validate_render(sc, cam, io, ro);
+    if (st != RT_OK) return st;
+    if (!d_mean_out) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is null");
+    HIP_TRY(hipSetDevice(sc->device));
+    hipStream_t stream = ro->stream ? (hipStream_t)ro->stream : sc->own_stream;
+    const bool profile = (ro->flags & RT_RENDER_PROFILE) != 0;
+    const uint32_t W = io->width, H = io->height;
+    const uint32_t tw = ro->tile_w ? ro->tile_w : 16, th = ro->tile_h ? ro->tile_h : 16;
+    const uint32_t ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th;
+
+    // pixels of the tiles this rank owns, tile by tile (tile_id % world_size == rank)
+    std::vector<uint32_t> owned;
+    for (uint32_t ty = 0; ty < nty; ++ty)
+        for (uint32_t tx = 0; tx < ntx; ++tx) {
+            if ((ty * ntx + tx) % ro->world_size != ro->rank) continue;
+            for (uint32_t y = ty * th; y < std::min(H, (ty + 1) * th); ++y)
+                for (uint32_t x = tx * tw; x < std::min(W, (tx + 1) * tw); ++x) owned.push_back(y * W + x);
+        }
+    const uint32_t n_owned = (uint32_t)owned.size();
+    const uint64_t spp = io->samples_per_pixel;
+    const uint32_t depth = (uint32_t)io->max_reflections;
+
+    HIP_TRY(hipMemsetAsync(d_mean_out, 0, (size_t)3 * W * H * sizeof(double), stream));
+    std::memset(&sc->prof, 0, sizeof(sc->prof));
+    if (n_owned == 0) { if (sync_at_end) HIP_TRY(hipStreamSynchronize(stream)); return RT_OK; }
+
+    uint64_t S = ro->samples_per_pass;
+    if (S == 0) S = std::max<uint64_t>(1, (8ull << 20) / n_owned);
+    S = std::min<uint64_t>(S, spp);
+    while (S > 1 && S * n_owned >= (1ull << 31)) S /= 2;
+    if (S * n_owned >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many pixels per rank for one pass");
+    const uint32_t n_counts = depth + 2;
+    if ((st = ensure_workspace(sc, S * n_owned, n_owned, n_counts)) != RT_OK) return st;
+    HIP_TRY(hipMemcpyAsync(sc->owned, owned.data(), n_owned * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(sc->accum, 0, (size_t)n_owned * 3 * sizeof(double), stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // `owned` is a stack vector
+
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
+    const uint32_t max_grid = (uint32_t)prop.multiProcessorCount * 8u;
+    const uint32_t tail_threshold = (uint32_t)prop.multiProcessorCount * 512u;
+    Launcher L{sc, stream, profile};
+    hipEvent_t ev;
+
+    PassParams P;
+    P.cam = *cam; P.width = W; P.height = H; P.n_owned = n_owned;
+    P.k0 = (uint32_t)ro->seed; P.k1 = (uint32_t)(ro->seed >> 32); P.max_depth = depth; P.owned = sc->owned;
+
+    const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;
+    int tail_from = force_tail ? 0 : -1;  // bounce at which k_tail takes over; -1 = not calibrated yet
+    for (uint64_t s0 = 0; s0 < spp; s0 += S) {
+        const uint32_t ns = (uint32_t)std::min<uint64_t>(S, spp - s0);
+        P.sample_base = (uint32_t)s0; P.n_paths = ns * n_owned;
+        const uint32_t grid_full = (P.n_paths + RT_BS - 1) / RT_BS;
+        const uint32_t grid = std::min(grid_full, max_grid);
+        if ((st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
+        hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, stream, P, sc->q[0], sc->counts, n_counts);
+        if ((st = L.end(ev)) != RT_OK) return st;
+        sc->prof.samples += P.n_paths; sc->prof.passes += 1;
+        int cur = 0;
+        // Queue lengths are read back (one sync per bounce) only while the hand-over point to k_tail is
+        // still unknown, when profiling, or when k_tail is disabled; otherwise nothing waits on the host.
+        const bool readback = tail_from < 0 || profile || force_wavefront;
+        uint32_t b = 0;
+        bool finished = false;
+        for (; b < depth; ++b) {
+            if (tail_from >= 0 && !force_wavefront && (int)b >= tail_from) break;
+            if ((st = L.begin(RT_K_TRAVERSE, &ev)) != RT_OK) return st;
+            hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->hits, b);
+            if ((st = L.end(ev)) != RT_OK) return st;
+            if ((st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->hits, sc->q[cur ^ 1], sc->counts + b,
+                               sc->counts + b + 1, sc->values, b);
+            if ((st = L.end(ev)) != RT_OK) return st;
+            cur ^= 1;
+            if (readback) {
+                HIP_TRY(hipMemcpyAsync(sc->h_counts, sc->counts + b, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                sc->prof.segments += sc->h_counts[0]; sc->prof.traverse_segments += sc->h_counts[0];
+                if (sc->h_counts[1] == 0) { finished = true; break; }
+                if (tail_from < 0 && !force_wavefront && sc->h_counts[1] <= tail_threshold) tail_from = (int)b + 1;
+            }
+        }
+        if (tail_from < 0 && !force_wavefront) tail_from = (int)depth;
+        if (!finished && b < depth) {
+            if ((st = L.begin(RT_K_TAIL, &ev)) != RT_OK) return st;
+            hipLaunchKernelGGL(k_tail, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->values, sc->counts + depth + 1, b);
+            if ((st = L.end(ev)) != RT_OK) return st;
+            if (profile) {
+                HIP_TRY(hipMemcpyAsync(sc->h_counts, sc->counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                sc->prof.segments += sc->h_counts[0];
+            }
+        }
+        if ((st = L.begin(RT_K_RESOLVE, &ev)) != RT_OK) return st;
+        hipLaunchKernelGGL(k_resolve, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, sc->values, sc->accum, n_owned, ns);
+        if ((st = L.end(ev)) != RT_OK) return st;
+    }
+    if ((st = L.begin(RT_K_FINALIZE, &ev)) != RT_OK) return st;
+    hipLaunchKernelGGL(k_finalize, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, sc->accum, sc->owned, n_owned, W, H, (double)spp, d_mean_out);
+    if ((st = L.end(ev)) != RT_OK) return st;
+    if (sync_at_end || profile) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (profile && (st = collect_profile(sc)) != RT_OK) return st;
+    }
+    return RT_OK;
+}
+
+extern "C" {
+
+rt_status rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out) {
+    return render_impl(sc, cam, io, ro, d_mean_out, false);
+}
+
+rt_status rt_quantise_device(rt_scene* sc, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream) {
+    if (!sc || !d_mean || !d_rgb_out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    hipStream_t s = stream ? (hipStream_t)stream : sc->own_stream;
+    if (n == 0) return RT_OK;
+    hipLaunchKernelGGL(k_quantise, dim3((uint32_t)((n + RT_BS - 1) / RT_BS)), dim3(RT_BS), 0, s, d_mean, n, d_rgb_out);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+rt_status rt_render(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, uint8_t* rgb_out, double* mean_out) {
+    rt_status st = validate_render(sc, cam, io, ro);
+    if (st != RT_OK) return st;
+    if (!rgb_out && !mean_out) return fail(RT_ERR_INVALID_ARGUMENT, "no output buffer");
+    HIP_TRY(hipSetDevice(sc->device));
+    const size_t n = (size_t)3 * io->width * io->height;
+    double* d_mean = nullptr; uint8_t* d_rgb = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_mean, n * sizeof(double)));
+    hipStream_t stream = ro->stream ? (hipStream_t)ro->stream : sc->own_stream;
+    st = render_impl(sc, cam, io, ro, d_mean, false);
+    if (st == RT_OK && rgb_out) {
+        hipError_t e = hipMalloc((void**)&d_rgb, n);
+        if (e != hipSuccess) st = fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(rgb)");
+        if (st == RT_OK) st = rt_quantise_device(sc, d_mean, n, d_rgb, stream);
+        if (st == RT_OK && hipMemcpyAsync(rgb_out, d_rgb, n, hipMemcpyDeviceToHost, stream) != hipSuccess) st = fail(RT_ERR_HIP, "copy of the image to the host failed");
+    }
+    if (st == RT_OK && mean_out && hipMemcpyAsync(mean_out, d_mean, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
+        st = fail(RT_ERR_HIP, "copy of the mean radiance to the host failed");
+    hipError_t e = hipStreamSynchronize(stream);
+    if (st == RT_OK && e != hipSuccess) st = fail(RT_ERR_HIP, std::string("render failed: ") + hipGetErrorString(e));
+    if (st == RT_OK && (ro->flags & RT_RENDER_PROFILE)) st = collect_profile(sc);
+    (void)hipFree(d_mean);
+    if (d_rgb) (void)hipFree(d_rgb);
+    return st;
+}
+
+rt_status rt_get_profile(rt_scene* sc, rt_profile* out) {
+    if (!sc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = sc->prof;
+    return RT_OK;
+}
+
+rt_status rt_intersect_batch(rt_scene* sc, int64_t scope, const rt_ray* rays, uint64_t n, float tmin, float tmax, uint64_t seed, const float* medium_u, rt_hit* out) {
+    if (!sc || (!rays && n) || (!out && n)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (scope >= (int64_t)sc->view.n_prims) return fail(RT_ERR_INVALID_ARGUMENT, "scope is not a primitive of this scene");
+    if (n == 0) return RT_OK;
+    if (n >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "batch too large");
+    HIP_TRY(hipSetDevice(sc->device));
+    rt_ray* d_rays = nullptr; rt_hit* d_out = nullptr; float* d_mu = nullptr;
+    rt_status st = RT_OK;
+    auto cleanup = [&]() { if (d_rays) (void)hipFree(d_rays); if (d_out) (void)hipFree(d_out); if (d_mu) (void)hipFree(d_mu); };
+#define TRY2(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+    TRY2(hipMalloc((void**)&d_rays, n * sizeof(rt_ray)));
+    TRY2(hipMalloc((void**)&d_out, n * sizeof(rt_hit)));
+    TRY2(hipMemcpy(d_rays, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    if (medium_u) { TRY2(hipMalloc((void**)&d_mu, n * sizeof(float))); TRY2(hipMemcpy(d_mu, medium_u, n * sizeof(float), hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_intersect_batch, dim3((uint32_t)((n + RT_BS - 1) / RT_BS)), dim3(RT_BS), 0, sc->own_stream, sc->view, scope, d_rays, n, tmin,
+                       tmax, (uint32_t)seed, (uint32_t)(seed >> 32), d_mu, d_out);
+    TRY2(hipGetLastError());
+    TRY2(hipStreamSynchronize(sc->own_stream));
+    TRY2(hipMemcpy(out, d_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    cleanup();
+    return st;
+}
+
+rt_status rt_camera_rays(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, uint64_t seed, uint64_t n, const uint32_t* px_i,
+                         const uint32_t* px_j, const uint32_t* sample, rt_ray* out) {
+    if (!sc || !cam || !io || ((!px_i || !px_j || !sample || !out) && n)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (io->width < 2 || io->height < 2) return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
+    if (n == 0) return RT_OK;
+    for (uint64_t k = 0; k < n; ++k)
+        if (px_i[k] >= io->width || px_j[k] >= io->height) return fail(RT_ERR_INVALID_ARGUMENT, "pixel out of range");
+    HIP_TRY(hipSetDevice(sc->device));
+    uint32_t* d_idx = nullptr; rt_ray* d_out = nullptr;
+    auto cleanup = [&]() { if (d_idx) (void)hipFree(d_idx); if (d_out) (void)hipFree(d_out); };
+    TRY2(hipMalloc((void**)&d_idx, 3 * n * sizeof(uint32_t)));
+    TRY2(hipMalloc((void**)&d_out, n * sizeof(rt_ray)));
+    TRY2(hipMemcpy(d_idx, px_i, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TRY2(hipMemcpy(d_idx + n, px_j, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TRY2(hipMemcpy(d_idx + 2 * n, sample, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_camera_rays, dim3((uint32_t)((n + RT_BS - 1) / RT_BS)), dim3(RT_BS), 0, sc->own_stream, *cam, io->width, io->height, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), n, d_idx, d_idx + n, d_idx + 2 * n, d_out);
+    TRY2(hipGetLastError());
+    TRY2(hipStreamSynchronize(sc->own_stream));
+    TRY2(hipMemcpy(out, d_out, n * sizeof(rt_ray), hipMemcpyDeviceToHost));
+    cleanup();
+    return RT_OK;
+#undef TRY2
+}
+
+}  // extern "C"

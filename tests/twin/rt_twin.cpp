@@ -1,0 +1,117 @@
+// rt_twin.cpp -- TEST INFRASTRUCTURE ONLY.  A g++ build of the per-ray functions of
+// raytracing_amd/csrc/rt_core.h (the same source the HIP kernels inline) driven by plain
+// host loops, so that intersection / shading / camera logic can be unit-tested against
+// the oracle on a machine without a GPU.  Nothing in the product loads this library.
+
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../raytracing_amd/csrc/rt_core.h"
+
+using namespace rt;
+
+namespace {
+SceneView view_of(const rt_scene_desc* D) {
+    SceneView V{};
+    V.prims = D->prims; V.spheres = D->spheres; V.rects = D->rects; V.boxes = D->boxes; V.xforms = D->xforms;
+    V.materials = D->materials; V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables; V.bvh = D->bvh;
+    V.n_prims = D->n_prims; V.n_bvh_nodes = D->n_bvh_nodes;
+    for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
+    return V;
+}
+}  // namespace
+
+extern "C" {
+
+void twin_intersect_batch(const rt_scene_desc* D, int64_t scope, const rt_ray* rays, uint64_t n, float tmin, float tmax, uint64_t seed,
+                          const float* medium_u, rt_hit* out) {
+    SceneView S = view_of(D);
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r; r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]); r.time = rays[i].time;
+        DrawKey key; key.k0 = (uint32_t)seed; key.k1 = (uint32_t)(seed >> 32); key.pixel = (uint32_t)i; key.sample = 0; key.bounce = 0;
+        key.medium_u = medium_u ? medium_u[i] : -1.0f;
+        float t = 0; uint32_t prim = 0; int side = 0; bool hit;
+        if (scope < 0) hit = closest_hit(S, r, tmin, tmax, key, t, prim, side);
+        else { prim = (uint32_t)scope; hit = prim_t(S, prim, r.o, r.d, tmin, tmax, r.time, key, t, side); }
+        rt_hit o; std::memset(&o, 0, sizeof(o));
+        if (hit) {
+            Hit h; prim_surface(S, prim, r.o, r.d, r.time, t, side, h);
+            o.hit = 1; o.prim = prim; o.t = h.t; o.u = h.u; o.v = h.v;
+            o.point[0] = h.point.x; o.point[1] = h.point.y; o.point[2] = h.point.z;
+            o.normal[0] = h.normal.x; o.normal[1] = h.normal.y; o.normal[2] = h.normal.z;
+            o.in_vec[0] = h.in_vec.x; o.in_vec[1] = h.in_vec.y; o.in_vec[2] = h.in_vec.z;
+        }
+        out[i] = o;
+    }
+}
+
+void twin_camera_rays(const rt_camera* cam, uint32_t width, uint32_t height, uint64_t seed, uint64_t n, const uint32_t* px_i, const uint32_t* px_j,
+                      const uint32_t* sample, rt_ray* out) {
+    for (uint64_t k = 0; k < n; ++k) {
+        Ray r = camera_ray(*cam, px_i[k], px_j[k], width, height, sample[k], (uint32_t)seed, (uint32_t)(seed >> 32));
+        out[k].origin[0] = r.o.x; out[k].origin[1] = r.o.y; out[k].origin[2] = r.o.z;
+        out[k].direction[0] = r.d.x; out[k].direction[1] = r.d.y; out[k].direction[2] = r.d.z; out[k].time = r.time;
+    }
+}
+
+// One shading event on a given hit record: returns scattered flag, colour, new ray.
+void twin_material_scatter(const rt_scene_desc* D, const rt_hit* h, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, int32_t* scattered,
+                           float* color, float* ray_o, float* ray_d) {
+    SceneView S = view_of(D);
+    Hit hh; hh.t = h->t; hh.u = h->u; hh.v = h->v; hh.prim = h->prim;
+    hh.point = v3(h->point[0], h->point[1], h->point[2]); hh.normal = v3(h->normal[0], h->normal[1], h->normal[2]);
+    hh.in_vec = v3(h->in_vec[0], h->in_vec[1], h->in_vec[2]);
+    DrawKey key; key.k0 = (uint32_t)seed; key.k1 = (uint32_t)(seed >> 32); key.pixel = pixel; key.sample = sample; key.bounce = bounce; key.medium_u = -1.0f;
+    Scatter sc = material_scatter(S, hh, key);
+    *scattered = sc.scattered ? 1 : 0;
+    color[0] = sc.color.x; color[1] = sc.color.y; color[2] = sc.color.z;
+    ray_o[0] = sc.o.x; ray_o[1] = sc.o.y; ray_o[2] = sc.o.z; ray_d[0] = sc.d.x; ray_d[1] = sc.d.y; ray_d[2] = sc.d.z;
+}
+
+float twin_perlin3(const uint8_t* perm256, float x, float y, float z) { return perlin3(perm256, v3(x, y, z)); }
+void twin_random_unit_vector(float u_phi, float u_z, float* out) { V3 r = random_unit_vector(u_phi, u_z); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void twin_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) {
+    U4 r = philox4x32_10(c[0], c[1], c[2], c[3], k[0], k[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+uint8_t twin_quantise(double x) { return quantise(x); }
+
+// The whole per-pixel loop (raygen -> closest_hit / shade_step per bounce -> f64 sum in sample order),
+// i.e. what the kernels compute, on host threads.  mean_out: 3*w*h doubles, top row first.
+void twin_render(const rt_scene_desc* D, const rt_camera* cam, uint32_t width, uint32_t height, uint64_t spp, uint64_t depth, uint64_t seed, int threads,
+                 double* mean_out) {
+    SceneView S = view_of(D);
+    std::atomic<uint32_t> next_row(0);
+    auto worker = [&]() {
+            for (;;) {
+            uint32_t row = next_row.fetch_add(1);
+            if (row >= height) break;
+            uint32_t j = height - 1 - row;
+            for (uint32_t i = 0; i < width; ++i) {
+                double acc[3] = {0, 0, 0};
+                for (uint64_t s = 0; s < spp; ++s) {
+                    Ray r = camera_ray(*cam, i, j, width, height, (uint32_t)s, (uint32_t)seed, (uint32_t)(seed >> 32));
+                    V3 thr = v3(1, 1, 1), value = v3(0, 0, 0);
+                    DrawKey key; key.k0 = (uint32_t)seed; key.k1 = (uint32_t)(seed >> 32); key.pixel = j * width + i; key.sample = (uint32_t)s; key.medium_u = -1.0f;
+                    for (uint32_t b = 0; b < depth; ++b) {
+                        key.bounce = b;
+                        float t = 0; uint32_t prim = 0; int side = 0;
+                        bool hit = closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);
+                        if (!shade_step(S, r, thr, key, hit, t, prim, side, b + 1 >= depth, value)) break;
+                    }
+                    acc[0] += (double)value.x; acc[1] += (double)value.y; acc[2] += (double)value.z;
+                }
+                size_t o = 3 * ((size_t)row * width + i);
+                for (int c = 0; c < 3; ++c) mean_out[o + c] = acc[c] / (double)spp;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+}
+
+}  // extern "C"
