@@ -94,12 +94,14 @@ typedef struct rt_box {
 } rt_box; /* 32 bytes */
 
 /* One rigid wrapper: Translated { offset } (shape.rs:98) or Rotated { axis,
- * angle } (shape.rs:101-105) with cos/sin of +angle precomputed in f64. */
+ * angle } (shape.rs:101-105) with cos/sin of +angle precomputed.  Kept in f64: a ray is
+ * moved into the shape's frame in f64 (see rt_core.h). */
 enum { RT_XF_TRANSLATE = 0, RT_XF_ROTATE_X = 1, RT_XF_ROTATE_Y = 2, RT_XF_ROTATE_Z = 3 };
 typedef struct rt_xform {
     uint32_t kind;
-    float a, b, c; /* translate: offset xyz; rotate: a = cos(angle), b = sin(angle), c unused */
-} rt_xform;        /* 16 bytes */
+    uint32_t reserved;
+    double a, b, c; /* translate: offset xyz; rotate: a = cos(angle), b = sin(angle), c unused */
+} rt_xform;         /* 32 bytes */
 
 /* Material (src/materials.rs:8-18). */
 enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_DIFFUSE_LIGHT = 3, RT_MAT_ISOTROPIC = 4 };

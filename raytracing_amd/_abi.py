@@ -37,7 +37,7 @@ class rt_box(C.Structure):
 
 
 class rt_xform(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("a", C.c_float), ("b", C.c_float), ("c", C.c_float)]
+    _fields_ = [("kind", C.c_uint32), ("reserved", C.c_uint32), ("a", C.c_double), ("b", C.c_double), ("c", C.c_double)]
 
 
 class rt_material(C.Structure):

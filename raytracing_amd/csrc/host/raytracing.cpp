@@ -350,11 +350,11 @@ void Scene::Impl::add_object(const Object& obj) {
     for (;;) {
         if (cur->kind == K::Flipped) { if (!medium) ++flips; cur = cur->inner.get(); }
         else if (cur->kind == K::Translated) {
-            rt_xform x{}; x.kind = RT_XF_TRANSLATE; x.a = (float)cur->offset[0]; x.b = (float)cur->offset[1]; x.c = (float)cur->offset[2];
+            rt_xform x{}; x.kind = RT_XF_TRANSLATE; x.a = cur->offset[0]; x.b = cur->offset[1]; x.c = cur->offset[2];
             xforms.push_back(x); cur = cur->inner.get();
         } else if (cur->kind == K::Rotated) {
             double a = cur->angle * (PI / 180.0);
-            rt_xform x{}; x.kind = RT_XF_ROTATE_X + (uint32_t)cur->axis; x.a = (float)std::cos(a); x.b = (float)std::sin(a);
+            rt_xform x{}; x.kind = RT_XF_ROTATE_X + (uint32_t)cur->axis; x.a = std::cos(a); x.b = std::sin(a);
             xforms.push_back(x); cur = cur->inner.get();
         } else if (cur->kind == K::ConstantMedium) {
             if (medium) throw std::invalid_argument("Scene: a ConstantMedium nested inside another ConstantMedium is not supported");

@@ -52,6 +52,7 @@ struct D3 { double x, y, z; };
 RT_HD D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_HD D3 d3(V3 a) { return d3((double)a.x, (double)a.y, (double)a.z); }
 RT_HD D3 d3(const double* p) { return d3(p[0], p[1], p[2]); }
+RT_HD D3 d3(D3 a) { return a; }
 RT_HD D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RT_HD D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_HD D3 operator*(D3 a, double s) { return d3(a.x * s, a.y * s, a.z * s); }
@@ -109,13 +110,40 @@ RT_HD void axis_perm(uint32_t axis, int& p1, int& p2, int& o) {  // shape.rs:138
     if (axis == 0) { p1 = 1; p2 = 2; o = 0; } else if (axis == 1) { p1 = 2; p2 = 0; o = 1; } else { p1 = 0; p2 = 1; o = 2; }
 }
 
-// Ray into the frame of the innermost shape: Translated subtracts the offset
-// from the origin (shape.rs:356-360), Rotated rotates origin and direction by
-// -angle (shape.rs:370-374); wrappers are applied outermost first.
-RT_HD void to_local(const SceneView& S, const rt_prim& P, V3& o, V3& d) {
+// Geometry below is written once for two precisions.  A primitive without Translated / Rotated
+// wrappers is tested in fp32: (height - origin) is then formed from the ray's own coordinates and is
+// accurate to an ulp of the difference.  Behind a wrapper the origin is first moved into the
+// shape's frame, which in fp32 would cost an ulp of the COORDINATE (1e-5 at 300 units, unbounded in t
+// for grazing rays), so wrapped primitives take the same code in f64 (sin/cos and offsets are kept in
+// f64 in rt_xform), as spheres always do.
+RT_HD double compd(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+RT_HD D3 ray_at(D3 o, D3 d, double t) { return (t <= 0.0) ? o : d3(fma(d.x, t, o.x), fma(d.y, t, o.y), fma(d.z, t, o.z)); }
+RT_HD D3 rotate_cs(D3 s, uint32_t kind, double c, double sn) {
+    D3 o = s;
+    if (kind == RT_XF_ROTATE_X) { o.y = s.y * c - s.z * sn; o.z = s.y * sn + s.z * c; }
+    else if (kind == RT_XF_ROTATE_Y) { o.z = s.z * c - s.x * sn; o.x = s.z * sn + s.x * c; }
+    else { o.x = s.x * c - s.y * sn; o.y = s.x * sn + s.y * c; }
+    return o;
+}
+RT_HD float get(V3 a, int i) { return comp(a, i); }
+RT_HD double get(D3 a, int i) { return compd(a, i); }
+RT_HD void put(V3& a, int i, float v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
+RT_HD void put(D3& a, int i, double v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }
+RT_HD float norm_of(V3 a) { return norm(a); }
+RT_HD double norm_of(D3 a) { return sqrt(dot(a, a)); }
+RT_HD float log_of(float x) { return logf(x); }
+RT_HD double log_of(double x) { return (double)logf((float)x); }
+template <class T> struct Lim;
+template <> struct Lim<float> { RT_HD static float inf() { return RT_INF_F; } RT_HD static float mx(float a, float b) { return fmaxf(a, b); } RT_HD static float mn(float a, float b) { return fminf(a, b); } };
+template <> struct Lim<double> { RT_HD static double inf() { return (double)RT_INF_F; } RT_HD static double mx(double a, double b) { return fmax(a, b); } RT_HD static double mn(double a, double b) { return fmin(a, b); } };
+
+// Ray into the frame of the innermost shape: Translated subtracts the offset from the origin
+// (shape.rs:356-360), Rotated rotates origin and direction by -angle (shape.rs:370-374); wrappers are
+// applied outermost first.
+RT_HD void to_local(const SceneView& S, const rt_prim& P, D3& o, D3& d) {
     for (uint32_t k = 0; k < P.xf_count; ++k) {
         const rt_xform X = S.xforms[P.xf_first + k];
-        if (X.kind == RT_XF_TRANSLATE) o = o - v3(X.a, X.b, X.c);
+        if (X.kind == RT_XF_TRANSLATE) o = o - d3(X.a, X.b, X.c);
         else { o = rotate_cs(o, X.kind, X.a, -X.b); d = rotate_cs(d, X.kind, X.a, -X.b); }
     }
 }
@@ -130,9 +158,9 @@ RT_HD D3 sphere_center(const rt_sphere& sp, bool moving, float time) {
     return c;
 }
 // Near root (-half_b - sqrt(disc)) / a of shape.rs:262-270; false when the discriminant is negative.
-RT_HD bool sphere_root(const rt_sphere& sp, bool moving, V3 o, V3 d, float time, double& t_out) {
+RT_HD bool sphere_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time, double& t_out) {
     D3 c = sphere_center(sp, moving, time);
-    D3 oc = d3(o) - c, dd = d3(d);
+    D3 oc = o - c;
     double a = dot(dd, dd);
     double half_b = dot(oc, dd);
     double cc = dot(oc, oc) - sp.radius * sp.radius;
@@ -141,21 +169,16 @@ RT_HD bool sphere_root(const rt_sphere& sp, bool moving, V3 o, V3 d, float time,
     t_out = (-half_b - sqrt(disc)) / a;
     return true;
 }
-RT_HD bool sphere_t(const rt_sphere& sp, bool moving, V3 o, V3 d, float tmin, float tmax, float time, double& t_out) {
-    double t;
-    if (!sphere_root(sp, moving, o, d, time, t)) return false;
-    if (t > (double)tmin && t < (double)tmax) { t_out = t; return true; }  // strict on both ends (shape.rs:271)
-    return false;
-}
 
-// Rectangle (shape.rs:309-332): inclusive interval and extents tests written so
-// that NaN and infinity flow exactly as in the reference.
-RT_HD bool rect_t(uint32_t axis, float x0, float y0, float x1, float y1, float height, V3 o, V3 d, float tmin, float tmax, float& t_out) {
+// Rectangle (shape.rs:309-332): inclusive interval and extents tests written so that NaN and
+// infinity flow exactly as in the reference.
+template <class T, class VT>
+RT_HD bool rect_t(uint32_t axis, T x0, T y0, T x1, T y1, T height, VT o, VT d, T tmin, T tmax, T& t_out) {
     int p1, p2, oo; axis_perm(axis, p1, p2, oo);
-    float t = (height - comp(o, oo)) / comp(d, oo);
+    T t = (height - get(o, oo)) / get(d, oo);
     if (t < tmin || t > tmax) return false;
-    V3 pt = ray_at(o, d, t);
-    float a = comp(pt, p1), b = comp(pt, p2);
+    VT pt = ray_at(o, d, t);
+    T a = get(pt, p1), b = get(pt, p2);
     if (a < x0 || a > x1 || b < y0 || b > y1) return false;
     t_out = t;
     return true;
@@ -173,52 +196,64 @@ RT_HD void box_side(const rt_box& B, int k, uint32_t& axis, float& x0, float& y0
 }
 // Box = Vec<Shape>::intersect over the six sides with shrinking tmax (shape.rs:17-34):
 // the smallest accepted t wins and a later side wins an exact tie.
-RT_HD bool box_t(const rt_box& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) {
+template <class T, class VT>
+RT_HD bool box_t(const rt_box& B, VT o, VT d, T tmin, T tmax, T& t_out, int& side) {
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        uint32_t axis; float x0, y0, x1, y1, h, t;
+        uint32_t axis; float x0, y0, x1, y1, h; T t;
         box_side(B, k, axis, x0, y0, x1, y1, h);
-        if (rect_t(axis, x0, y0, x1, y1, h, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
+        if (rect_t<T, VT>(axis, (T)x0, (T)y0, (T)x1, (T)y1, (T)h, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
     }
     return any;
 }
 
 // Ray parameter of the innermost shape for a ray already in its frame.
-RT_HD bool geom_t(const SceneView& S, const rt_prim& P, V3 o, V3 d, float tmin, float tmax, float time, float& t, int& side) {
+template <class T, class VT>
+RT_HD bool geom_t(const SceneView& S, const rt_prim& P, VT o, VT d, T tmin, T tmax, float time, T& t, int& side) {
     side = 0;
     if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
         double t64;
-        if (!sphere_t(S.spheres[P.geom_index], P.geom == RT_GEOM_MOVING_SPHERE, o, d, tmin, tmax, time, t64)) return false;
-        t = (float)t64;
+        if (!sphere_root(S.spheres[P.geom_index], P.geom == RT_GEOM_MOVING_SPHERE, d3(o), d3(d), time, t64)) return false;
+        if (!(t64 > (double)tmin && t64 < (double)tmax)) return false;  // strict on both ends (shape.rs:271)
+        t = (T)t64;
         return true;
     }
     if (P.geom == RT_GEOM_RECT) {
         const rt_rect R = S.rects[P.geom_index];
-        return rect_t(R.axis, R.x0, R.y0, R.x1, R.y1, R.height, o, d, tmin, tmax, t);
+        return rect_t<T, VT>(R.axis, (T)R.x0, (T)R.y0, (T)R.x1, (T)R.y1, (T)R.height, o, d, tmin, tmax, t);
     }
-    return box_t(S.boxes[P.geom_index], o, d, tmin, tmax, t, side);
+    return box_t<T, VT>(S.boxes[P.geom_index], o, d, tmin, tmax, t, side);
 }
 
-// Intersection::intersect reduced to the accepted ray parameter (plus the box
-// side).  ConstantMedium follows shape.rs:386-410 step by step.
-RT_HD bool prim_t(const SceneView& S, uint32_t prim, V3 o, V3 d, float tmin, float tmax, float time, const DrawKey& key, float& t, int& side) {
-    const rt_prim P = S.prims[prim];
-    to_local(S, P, o, d);
-    if (!(P.flags & RT_PRIM_MEDIUM)) return geom_t(S, P, o, d, tmin, tmax, time, t, side);
-    float t1, t2; int s_;
-    if (!geom_t(S, P, o, d, -RT_INF_F, RT_INF_F, time, t1, s_)) return false;
-    if (!geom_t(S, P, o, d, t1 + 0.001f, RT_INF_F, time, t2, s_)) return false;
-    t1 = fmaxf(t1, tmin);
-    t2 = fminf(t2, tmax);
+// Intersection::intersect reduced to the accepted ray parameter (plus the box side) for a ray in the
+// shape's frame.  ConstantMedium follows shape.rs:386-410 step by step.
+template <class T, class VT>
+RT_HD bool local_t(const SceneView& S, const rt_prim& P, uint32_t prim, VT o, VT d, T tmin, T tmax, float time, const DrawKey& key, T& t, int& side) {
+    if (!(P.flags & RT_PRIM_MEDIUM)) return geom_t<T, VT>(S, P, o, d, tmin, tmax, time, t, side);
+    T t1, t2; int s_;
+    if (!geom_t<T, VT>(S, P, o, d, -Lim<T>::inf(), Lim<T>::inf(), time, t1, s_)) return false;
+    if (!geom_t<T, VT>(S, P, o, d, t1 + (T)0.001, Lim<T>::inf(), time, t2, s_)) return false;
+    t1 = Lim<T>::mx(t1, tmin);
+    t2 = Lim<T>::mn(t2, tmax);
     if (t1 >= t2) return false;
-    t1 = fmaxf(t1, 0.0f);
-    float length = norm(d);
-    float inside = (t2 - t1) * length;
-    float hit_distance = -1.0f / P.density * logf(medium_variate(key, prim));
+    t1 = Lim<T>::mx(t1, (T)0);
+    T length = norm_of(d);
+    T inside = (t2 - t1) * length;
+    T hit_distance = (T)-1 / (T)P.density * log_of((T)medium_variate(key, prim));
     if (hit_distance > inside) return false;
     t = t1 + hit_distance / length;
     side = 0;
+    return true;
+}
+RT_HD bool prim_t(const SceneView& S, uint32_t prim, V3 o, V3 d, float tmin, float tmax, float time, const DrawKey& key, float& t, int& side) {
+    const rt_prim P = S.prims[prim];
+    if (P.xf_count == 0) return local_t<float, V3>(S, P, prim, o, d, tmin, tmax, time, key, t, side);
+    D3 lo = d3(o), ld = d3(d);
+    to_local(S, P, lo, ld);
+    double t64;
+    if (!local_t<double, D3>(S, P, prim, lo, ld, (double)tmin, (double)tmax, time, key, t64, side)) return false;
+    t = (float)t64;
     return true;
 }
 
@@ -228,42 +263,31 @@ struct Hit {  // IntersectionPoint (shape.rs:539-550)
     uint32_t prim;
 };
 
-// The rest of the IntersectionPoint for an accepted (prim, t, side): point,
-// normal, in_vec and surface coordinates, carried back out through the wrappers
-// (Rotated rotates point / normal / in_vec by +angle, shape.rs:378-383;
-// Translated adds the offset to the point, shape.rs:364-367).
-RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float time, float t, int side, Hit& h) {
-    const rt_prim P = S.prims[prim];
-    const V3 wd = d;
-    to_local(S, P, o, d);
-    V3 n, pt;
-    float u = 0.0f, v = 0.0f;
-    uint32_t back_from = P.xf_count;  // wrappers [0, back_from) are undone on the way out
+// Point, normal and surface coordinates in the shape's frame for an accepted (t, side).  Runs once per
+// path segment (not per candidate), in f64: the ray parameter is re-derived in f64 (t is its fp32
+// rounding), so the point is the reference's point rounded once rather than origin + fp32(t) * direction.
+RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float time, float t, int side, D3& pt, D3& n, double& u, double& v) {
+    u = 0.0; v = 0.0;
     if (P.flags & RT_PRIM_MEDIUM) {
-        pt = ray_at(o, d, t);
-        // the medium's hit lives in the frame of the ConstantMedium wrapper; undo the inner wrappers for the point
-        for (uint32_t k = P.xf_count; k > P.xf_outer; --k) {
-            const rt_xform X = S.xforms[P.xf_first + k - 1];
-            if (X.kind == RT_XF_TRANSLATE) pt = pt + v3(X.a, X.b, X.c); else pt = rotate_cs(pt, X.kind, X.a, X.b);
-        }
-        n = v3(1.0f, 0.0f, 0.0f);  // shape.rs:413
-        back_from = P.xf_outer;
+        pt = ray_at(o, d, (double)t);
+        n = d3(1.0, 0.0, 0.0);  // shape.rs:413
     } else if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
         const rt_sphere sp = S.spheres[P.geom_index];
-        bool moving = P.geom == RT_GEOM_MOVING_SPHERE;
+        const bool moving = P.geom == RT_GEOM_MOVING_SPHERE;
         double t64 = (double)t;
-        sphere_root(sp, moving, o, d, time, t64);  // re-solve: the point and normal need the f64 root
+        sphere_root(sp, moving, o, d, time, t64);
         D3 c = sphere_center(sp, moving, time);
-        D3 p = (t64 <= 0.0) ? d3(o) : d3(o) + d3(d) * t64;
+        D3 p = ray_at(o, d, t64);
         D3 pc = p - c;
-        double inv_len = 1.0 / sqrt(dot(pc, pc));
-        n = v3(pc * inv_len);
+        n = pc * (1.0 / sqrt(dot(pc, pc)));
         D3 q = pc * (1.0 / sp.radius);  // shape.rs:275 divides by the signed radius
         float phi = atan2f((float)q.z, (float)q.x);
-        float theta = atan2f((float)q.y, (float)sqrt(q.x * q.x + q.z * q.z));  // = asin(q.y) for unit q, well conditioned at the poles
-        u = 1.0f - (phi + RT_PI_F) / (2.0f * RT_PI_F);
-        v = (theta + RT_PI_F / 2.0f) / RT_PI_F;
-        pt = v3(p);
+        // theta = asin(q.y) as atan2(q.y, sqrt(1 - q.y^2)), the square root in f64: exact for every |q.y| <= 1,
+        // NaN beyond like asin, and without fp32 asin's loss of accuracy near the poles
+        float theta = atan2f((float)q.y, (float)sqrt(1.0 - q.y * q.y));
+        u = (double)(1.0f - (phi + RT_PI_F) / (2.0f * RT_PI_F));
+        v = (double)((theta + RT_PI_F / 2.0f) / RT_PI_F);
+        pt = p;
     } else {
         uint32_t axis; float x0, y0, x1, y1, hgt; bool flip_side = false;
         if (P.geom == RT_GEOM_RECT) {
@@ -274,22 +298,34 @@ RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float tim
             flip_side = (side & 1) == 0;  // the x0 / y0 / z0 sides are Flipped (outward normals)
         }
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
-        pt = ray_at(o, d, t);
-        // The reference's f64 point lies on the plane to ~1e-13; fp32 would leave it up to an ulp of the
-        // coordinate away, enough for a grazing follow-up ray to hit the same plane again beyond tmin.
-        if (t > 0.0f) { if (oo == 0) pt.x = hgt; else if (oo == 1) pt.y = hgt; else pt.z = hgt; }
-        u = (comp(pt, p1) - x0) / (x1 - x0);
-        v = (comp(pt, p2) - y0) / (y1 - y0);
-        float s = flip_side ? -1.0f : 1.0f;
-        n = v3(oo == 0 ? s : 0.0f, oo == 1 ? s : 0.0f, oo == 2 ? s : 0.0f);
+        const double t64 = ((double)hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321
+        pt = ray_at(o, d, t64);
+        u = (compd(pt, p1) - (double)x0) / ((double)x1 - (double)x0);
+        v = (compd(pt, p2) - (double)y0) / ((double)y1 - (double)y0);
+        const double s = flip_side ? -1.0 : 1.0;
+        n = d3(oo == 0 ? s : 0.0, oo == 1 ? s : 0.0, oo == 2 ? s : 0.0);
     }
-    for (uint32_t k = back_from; k > 0; --k) {
+}
+
+// The rest of the IntersectionPoint for an accepted (prim, t, side), carried back out through the
+// wrappers (Rotated rotates point / normal / in_vec by +angle, shape.rs:378-383; Translated adds the
+// offset to the point, shape.rs:364-367).
+RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float time, float t, int side, Hit& h) {
+    const rt_prim P = S.prims[prim];
+    h.t = t; h.in_vec = normed(d); h.prim = prim;
+    D3 lo = d3(o), ld = d3(d);
+    to_local(S, P, lo, ld);
+    D3 pt, n; double u, v;
+    local_surface(S, P, lo, ld, time, t, side, pt, n, u, v);
+    // a medium's hit lives in the frame of the ConstantMedium wrapper: the inner wrappers move only the point
+    const uint32_t n_from = (P.flags & RT_PRIM_MEDIUM) ? P.xf_outer : P.xf_count;
+    for (uint32_t k = P.xf_count; k > 0; --k) {
         const rt_xform X = S.xforms[P.xf_first + k - 1];
-        if (X.kind == RT_XF_TRANSLATE) pt = pt + v3(X.a, X.b, X.c);
-        else { pt = rotate_cs(pt, X.kind, X.a, X.b); n = rotate_cs(n, X.kind, X.a, X.b); }
+        if (X.kind == RT_XF_TRANSLATE) pt = pt + d3(X.a, X.b, X.c);
+        else { pt = rotate_cs(pt, X.kind, X.a, X.b); if (k <= n_from) n = rotate_cs(n, X.kind, X.a, X.b); }
     }
-    if (P.flags & RT_PRIM_FLIP) n = -n;
-    h.t = t; h.u = u; h.v = v; h.point = pt; h.normal = n; h.in_vec = normed(wd); h.prim = prim;
+    if (P.flags & RT_PRIM_FLIP) n = n * -1.0;
+    h.point = v3(pt); h.normal = v3(n); h.u = (float)u; h.v = (float)v;
 }
 
 // --------------------------------------------------------------- traversal

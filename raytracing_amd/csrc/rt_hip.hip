@@ -536,7 +536,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
 
     const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;
     int tail_from = force_tail ? 0 : -1;  // bounce at which k_tail takes over; -1 = not calibrated yet
-    for (uint64_t s0 = 0; s0 < spp; s0 += S) {
+    // max_reflections == 0: ray_color's loop body never runs and every sample is black (lib.rs:89, :103)
+    for (uint64_t s0 = 0; s0 < spp && depth > 0; s0 += S) {
         const uint32_t ns = (uint32_t)std::min<uint64_t>(S, spp - s0);
         P.sample_base = (uint32_t)s0; P.n_paths = ns * n_owned;
         const uint32_t grid_full = (P.n_paths + RT_BS - 1) / RT_BS;

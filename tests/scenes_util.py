@@ -1,0 +1,117 @@
+"""Shared helpers for the parity tests: shape zoo, ray generators, hit-record comparison."""
+import numpy as np
+
+import raytracing_amd as rt
+
+EXAMPLES = ["random_spheres", "cornell", "perlin", "cornell_smoke", "final_scene"]
+# Hit-record tolerance: |got - oracle| <= TOL * max(1, |oracle|) on t, normal, in_vec, u, v.  The point is
+# origin + t * direction with t held in fp32, so its error scales with the ray, not with the coordinate it
+# lands on: |got - oracle| <= TOL * max(1, |oracle point|_inf, |ray origin|_inf).
+TOL = 1e-5
+
+
+def shape_zoo():
+    """(name, Shape) pairs covering every Shape variant and wrapper nesting (shape.rs:62-106)."""
+    S = rt.Shape
+    box = S.new_box((0, 0, 0), (165, 330, 165))
+    return [
+        ("sphere", S.Sphere((1.0, 2.0, -3.0), 2.5)),
+        ("sphere_big", S.Sphere((0.0, -1000.0, 0.0), 1000.0)),
+        ("moving_sphere", S.sphere(0.7, (0.0, (0.0, 0.5, 0.0)), (1.0, (0.3, 1.1, -0.2)))),
+        ("rect_x", S.rectangle((2.0, -1.0, -2.0), (2.0, 3.0, 4.0))),
+        ("rect_y", S.rectangle((-3.0, 0.5, -1.0), (4.0, 0.5, 2.0))),
+        ("rect_z", S.rectangle((-1.0, -2.0, 1.5), (3.0, 2.0, 1.5))),
+        ("rect_flipped", S.rectangle((0.0, 0.0, 5.0), (5.0, 5.0, 5.0)).flipped()),
+        ("box_cube", S.new_box((-1, -1, -1), (2, 2, 2))),
+        ("box_slab", S.new_box((0, 0, -100), (100, 41.25, 0))),  # x and z ranges differ: y sides carry swapped extents
+        ("box_rot_y_trans", box.rotated(rt.AXIS_Y, 15.0).translated((265, 0, 295))),
+        ("box_rot_x", S.new_box((0, 0, 0), (3, 2, 1)).rotated(rt.AXIS_X, -33.0)),
+        ("box_rot_z_rot_y", S.new_box((-1, 0, 0), (2, 2, 3)).rotated(rt.AXIS_Z, 70.0).rotated(rt.AXIS_Y, 10.0).translated((0.5, -0.5, 2))),
+        ("sphere_rot_y", S.Sphere((0, 0, 0), 2.0).rotate(rt.AXIS_Y, 45.0)),
+        ("sphere_trans_flipped", S.Sphere((1, 1, 1), 1.5).translated((-2, 0, 3)).flipped()),
+        ("medium_box", S.ConstantMedium(S.new_box((0, 0, 0), (165, 165, 165)).rotated(rt.AXIS_Y, -18.0).translated((130, 0, 65)), 0.01)),
+        ("medium_cube", S.ConstantMedium(S.new_box((-2, -2, -2), (2, 2, 2)), 0.4)),
+        ("medium_sphere", S.ConstantMedium(S.Sphere((0, 0, 0), 3.0), 0.5)),  # never hit (near root twice)
+        ("medium_wrapped", S.ConstantMedium(S.new_box((-1, -1, -1), (1, 1, 1)).rotated(rt.AXIS_Z, 30.0), 0.8).rotated(rt.AXIS_X, 20.0).translated((1, 2, 3)).flipped()),
+    ]
+
+
+def bound_of(shape):
+    from oracle_lib import OracleShape
+    return OracleShape(shape).bound()
+
+
+def rays_at_box(rng, mn, mx, n, spread=1.5):
+    """n rays with origins around (and partly inside) the box [mn, mx], aimed at random points in it."""
+    mn, mx = np.asarray(mn, float), np.asarray(mx, float)
+    mn, mx = np.maximum(mn, -5000.0), np.minimum(mx, 5000.0)
+    c, e = 0.5 * (mn + mx), np.maximum(0.5 * (mx - mn), 0.5)
+    o = c + (rng.random((n, 3)) * 2 - 1) * e * spread * 2
+    inside = rng.random(n) < 0.25
+    o[inside] = (c + (rng.random((n, 3)) * 2 - 1) * e)[inside]
+    target = c + (rng.random((n, 3)) * 2 - 1) * e * 1.1
+    d = target - o
+    d *= (0.2 + 2.0 * rng.random((n, 1))) / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
+    # a share of axis-parallel rays: zeros in the direction exercise the inf / NaN paths
+    ax = rng.random(n) < 0.05
+    k = rng.integers(0, 3, n)
+    for i in np.where(ax)[0]:
+        d[i, k[i]] = 0.0
+    t = rng.random(n)
+    return o.astype(np.float32), d.astype(np.float32), t.astype(np.float32)
+
+
+def compare_hits(got, ref, what="", tol=TOL, allow_flag_mismatch=0.0, allow_prim_mismatch=0.0, origins=None):
+    """Asserts hit records `got` (rt_hit, fp32) agree with the oracle's `ref` (f64)."""
+    n = len(ref)
+    flag_mis = got["hit"] != ref["hit"]
+    assert flag_mis.sum() <= allow_flag_mismatch * n, f"{what}: {int(flag_mis.sum())}/{n} hit/miss mismatches, first at {np.where(flag_mis)[0][:5]}"
+    both = (got["hit"] == 1) & (ref["hit"] == 1)
+    prim_mis = both & (got["prim"] != ref["prim"])
+    assert prim_mis.sum() <= allow_prim_mismatch * n, f"{what}: {int(prim_mis.sum())}/{n} primitive mismatches, first at {np.where(prim_mis)[0][:5]}"
+    same = both & ~prim_mis
+    worst = {}
+    for f in ("t", "point", "normal", "in_vec", "u", "v"):
+        a, b = got[f][same].astype(np.float64), ref[f][same]
+        scale = np.maximum(1.0, np.abs(b))
+        if f == "point":
+            scale = np.maximum(1.0, np.abs(b).max(axis=1, keepdims=True))
+            if origins is not None:
+                scale = np.maximum(scale, np.abs(np.asarray(origins, np.float64)[same]).max(axis=1, keepdims=True))
+        with np.errstate(invalid="ignore"):
+            err = np.abs(a - b) / scale
+        err[(np.isnan(a) & np.isnan(b)) | (a == b)] = 0.0   # NaN on both sides, or the same infinity
+        worst[f] = float(err.max()) if err.size else 0.0
+        assert not np.isnan(err).any(), f"{what}: NaN mismatch in {f}"
+        assert worst[f] <= tol, f"{what}: {f} off by {worst[f]:.3e} (> {tol}) at ray {np.where(same)[0][np.unravel_index(np.argmax(err), err.shape)[0]]}"
+    return int(same.sum()), worst
+
+
+def path_rays(oscene, oco, width, height, seed, n, bounces, rng):
+    """Rays as the renderer meets them: camera rays and their scattered successors for a few
+    bounces, produced by the oracle (so both sides of a parity test see the same fp32 rays)."""
+    import ctypes as C
+    from oracle_lib import oracle, oracle_camera_rays
+    lib = oracle()
+    pi, pj, ss = rng.integers(0, width, n), rng.integers(0, height, n), rng.integers(0, 64, n)
+    o, d, t = oracle_camera_rays(oco, width, height, seed, pi, pj, ss)
+    o, d, t = o.astype(np.float32), d.astype(np.float32), t.astype(np.float32)
+    out = [(o, d, t)]
+    ids = np.arange(n)
+    for b in range(bounces):
+        h = oscene.intersect(o, d, t, seed=seed)
+        idx = np.where(h["hit"] == 1)[0]
+        no, nd, keep = np.zeros((len(idx), 3), np.float32), np.zeros((len(idx), 3), np.float32), []
+        for j, k in enumerate(idx):
+            hk = h[k:k + 1].copy()
+            sc, col, ro, rd = C.c_int32(), (C.c_double * 3)(), (C.c_double * 3)(), (C.c_double * 3)()
+            lib.orc_scene_scatter(oscene.h, hk.ctypes.data, seed, int(ids[k]), 0, b, C.byref(sc), col, ro, rd)
+            if sc.value and np.isfinite(np.array(rd)).all():
+                keep.append(j)
+                no[j], nd[j] = ro, rd
+        keep = np.array(keep, dtype=int)
+        if len(keep) == 0:
+            break
+        o, d, t, ids = no[keep], nd[keep], t[idx][keep], ids[idx][keep]
+        out.append((o, d, t))
+    return out
