@@ -52,12 +52,13 @@ def algorithmic_flops(cnt):
 
 
 def cpu_baseline_and_work(earth):
-    """Times the oracle on final_scene at 160x160, 32 spp (819 200 samples, the full view), then counts work on a smaller run."""
+    """Times the oracle on final_scene at 320x320, 96 spp (9.8 M samples of the full view, 10-30 s on 16 cores),
+    then counts work on a smaller run."""
     from oracle_lib import OracleScene
     threads = min(16, os.cpu_count() or 1)
     osc, oco = OracleScene.example("final_scene", 1, earth)
-    w = h = 160
-    spp = 32
+    w = h = 320
+    spp = 96
     _, _, secs, _ = osc.render(oco, w, h, spp, DEPTH, seed=1, threads=threads, shade_every=True)
     _, _, _, cnt = osc.render(oco, 96, 96, 8, DEPTH, seed=1, threads=threads, counters=True)
     base = {"value": round(w * h * spp / secs / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",

@@ -171,7 +171,7 @@ def test_full_size_properties(earth):
     rgb, mean = sc.render(cam, io, rt.RenderOptions(seed=1, flags=_abi.RT_RENDER_PROFILE), want_mean=True)
     prof = sc.profile()
     assert prof["samples"] == 800 * 800 * 4 and prof["segments"] >= prof["samples"]
-    assert np.isfinite(mean).all() and mean.min() >= 0.0          # no negative textures reach the camera here
+    assert np.isfinite(mean).all()   # (means may be negative: the noise texture returns values in [-1, 1], textures.rs:57)
     assert np.array_equal(rgb, np.minimum(np.floor(np.sqrt(np.clip(mean, 0, 1)) * 255.999), 255).astype(np.uint8))
     halves = [sc.render(cam, io, rt.RenderOptions(seed=1, rank=r, world_size=2), want_mean=True)[1] for r in range(2)]
     assert np.array_equal(halves[0] + halves[1], mean)
