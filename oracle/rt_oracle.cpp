@@ -146,8 +146,11 @@ static inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
     }
     return c;
 }
-// 24-bit uniform in [0,1): exactly representable in fp32 and f64 alike.
-static inline double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
+// Uniform variate in the open interval (0,1): the 2^23 odd multiples of 2^-24, exactly representable in fp32
+// and f64 alike (so the GPU path can consume identical variates).  Never 0 or 1: with rand's 53-bit variates
+// the reference all but never draws the endpoints either (z = -1 in OnUnitSphere gives the exact pole, and
+// "random_unit_vector + normal" = 0 on a z-facing surface turns the whole pixel NaN).
+static inline double u01(uint32_t x) { return (double)((x >> 9) * 2u + 1u) * (1.0 / 16777216.0); }
 
 static const uint32_t TAG_CAMERA = 0xFFFFFFFFu;
 

@@ -25,6 +25,11 @@
 #define RT_HD inline
 #endif
 
+// Optional work counters for host-side analysis builds (empty in the product).
+#ifndef RT_COUNT
+#define RT_COUNT(name)
+#endif
+
 namespace rt {
 
 #define RT_PI_F 3.14159265358979323846f
@@ -83,8 +88,12 @@ RT_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     }
     U4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
 }
-// 24-bit uniform in [0,1), exact in fp32.
-RT_HD float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// Uniform variate in the open interval (0,1): the 2^23 odd multiples of 2^-24, exact in fp32 (and in the
+// f64 oracle).  Never 0: the reference draws 53-bit variates, for which z = -1 in its sphere sampler (and the
+// zero vector "random_unit + normal" that follows on a z-facing surface, NaN for the whole pixel) has
+// probability ~1e-16 per draw; with a 24-bit grid that includes 0 it would be 6e-8, thousands of black
+// pixels in a 10 000-spp frame.
+RT_HD float u01(uint32_t x) { return (float)((x >> 9) * 2u + 1u) * (1.0f / 16777216.0f); }
 
 // Identity of the path segment being traced; keys every random draw.
 struct DrawKey {
@@ -206,6 +215,39 @@ RT_HD bool box_t(const rt_box& B, VT o, VT d, T tmin, T tmax, T& t_out, int& sid
         if (rect_t<T, VT>(axis, (T)x0, (T)y0, (T)x1, (T)y1, (T)h, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
     }
     return any;
+}
+// The same six sides in fp32 with the plane parameters given: q[2a + s] = (bound[s][a] - origin[a]) * (1 / direction[a]).
+// Every fp32 box test and every exact leaf test (closest_hit) forms its parameters by this one expression, so two
+// boxes that share a face see bit-identical t on it, which is what the reference's tie rule needs.
+RT_HD void box_quotients(const float* bmin, const float* bmax, V3 o, V3 inv, float* q) {
+    q[0] = (bmin[0] - o.x) * inv.x; q[1] = (bmax[0] - o.x) * inv.x;
+    q[2] = (bmin[1] - o.y) * inv.y; q[3] = (bmax[1] - o.y) * inv.y;
+    q[4] = (bmin[2] - o.z) * inv.z; q[5] = (bmax[2] - o.z) * inv.z;
+}
+RT_HD bool box_sides_q(const float* bmin, const float* bmax, V3 o, V3 d, const float* q, float tmin, float tmax, float& t_out, int& side) {
+    bool any = false;
+    rt_box B;
+    B.min[0] = bmin[0]; B.min[1] = bmin[1]; B.min[2] = bmin[2]; B.max[0] = bmax[0]; B.max[1] = bmax[1]; B.max[2] = bmax[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        uint32_t axis; float x0, y0, x1, y1, h;
+        box_side(B, k, axis, x0, y0, x1, y1, h);
+        int p1, p2, oo; axis_perm(axis, p1, p2, oo);
+        const float t = q[k];
+        if (t < tmin || t > tmax) continue;
+        V3 pt = ray_at(o, d, t);
+        float a = comp(pt, p1), b = comp(pt, p2);
+        if (a < x0 || a > x1 || b < y0 || b > y1) continue;
+        tmax = t; t_out = t; side = k; any = true;
+    }
+    return any;
+}
+template <>
+RT_HD bool box_t<float, V3>(const rt_box& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) {
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float q[6];
+    box_quotients(B.min, B.max, o, inv, q);
+    return box_sides_q(B.min, B.max, o, d, q, tmin, tmax, t_out, side);
 }
 
 // Ray parameter of the innermost shape for a ray already in its frame.
@@ -340,43 +382,90 @@ struct Ray {
 // tmax, and a later accepted hit replaces an earlier one.  Leaves are reached in the
 // reference's left-then-right order.  Node boxes are widened by the host, so the fp32 slab
 // test errs on the side of visiting.
+//
+// Bits of rt_bvh_node.prim on a leaf: the primitive id (RT_NODE_PRIM_MASK), RT_BVH_EXACT from the host,
+// and RT_NODE_PLAIN_BOX, which the library sets on its device copy for an exact leaf whose primitive is a
+// box without wrappers or medium: the leaf's own box then is the geometry and nothing else is fetched.
+#define RT_NODE_PRIM_MASK 0x1FFFFFFFu
+#define RT_NODE_PLAIN_BOX 0x40000000u
+
+struct Walk {
+    uint32_t i;     // next node to look at
+    float tmax;     // shrinking upper end of the ray interval
+    float t;        // accepted hit so far
+    uint32_t prim;
+    int side;
+    bool found;
+};
+RT_HD void walk_init(Walk& w, float tmax) { w.i = 0; w.tmax = tmax; w.t = 0.0f; w.prim = 0; w.side = 0; w.found = false; }
+
+// One node step.  Returns the leaf's prim field when the ray now stands on a leaf whose primitive has to be
+// tried (w.i already points past it), RT_BVH_NONE otherwise.  Requires w.i < S.n_bvh_nodes.
+RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w) {
+    const rt_bvh_node N = S.bvh[w.i];
+    RT_COUNT(nodes);
+    float x0 = fmaf(N.min[0], inv.x, -oi.x), x1 = fmaf(N.max[0], inv.x, -oi.x);
+    float y0 = fmaf(N.min[1], inv.y, -oi.y), y1 = fmaf(N.max[1], inv.y, -oi.y);
+    float z0 = fmaf(N.min[2], inv.z, -oi.z), z1 = fmaf(N.max[2], inv.z, -oi.z);
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), w.tmax));
+    if (!(tn <= tf)) { w.i = N.skip; return RT_BVH_NONE; }
+    w.i += 1;
+    return N.prim;
+}
+
+// The primitive test of the leaf at node w.i - 1: Object::scatter's intersect (lib.rs:284-285) behind the
+// leaf's own bounding-box test (lib.rs:236-240).
+RT_HD void walk_leaf(const SceneView& S, const Ray& r, V3 inv, float tmin, const DrawKey& key, uint32_t leaf, Walk& w) {
+    const uint32_t prim = leaf & RT_NODE_PRIM_MASK;
+    RT_COUNT(leaves);
+    float t; int side;
+    if (leaf & RT_BVH_EXACT) {
+        // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: (bound - origin) over the direction,
+        // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
+        const rt_bvh_node N = S.bvh[w.i - 1];
+        float q[6];
+        box_quotients(N.min, N.max, r.o, inv, q);
+        float lo = tmin, hi = w.tmax;
+        lo = fmaxf(r.d.x < 0.0f ? q[1] : q[0], lo); hi = fminf(r.d.x < 0.0f ? q[0] : q[1], hi);
+        bool enter = !(hi <= lo);
+        lo = fmaxf(r.d.y < 0.0f ? q[3] : q[2], lo); hi = fminf(r.d.y < 0.0f ? q[2] : q[3], hi);
+        enter = enter && !(hi <= lo);
+        lo = fmaxf(r.d.z < 0.0f ? q[5] : q[4], lo); hi = fminf(r.d.z < 0.0f ? q[4] : q[5], hi);
+        enter = enter && !(hi <= lo);
+        if (!enter) return;
+        RT_COUNT(prim_tests);
+        bool plain = (leaf & RT_NODE_PLAIN_BOX) != 0;
+        if (!plain) {
+            const rt_prim P = S.prims[prim];
+            plain = P.geom == RT_GEOM_BOX && P.xf_count == 0 && !(P.flags & RT_PRIM_MEDIUM);
+        }
+        if (plain) {  // the leaf's box is the box: same arithmetic as box_t<float>, without fetching it
+            if (box_sides_q(N.min, N.max, r.o, r.d, q, tmin, w.tmax, t, side)) { w.tmax = t; w.t = t; w.prim = prim; w.side = side; w.found = true; }
+            return;
+        }
+    } else {
+        RT_COUNT(prim_tests);
+    }
+    if (prim_t(S, prim, r.o, r.d, tmin, w.tmax, r.time, key, t, side)) { w.tmax = t; w.t = t; w.prim = prim; w.side = side; w.found = true; }
+}
+
+// The whole walk for one ray.  Two nested loops on purpose: the inner loop only steps over nodes until it
+// stands on a leaf, the outer loop runs the (much longer) primitive test, so the lanes of a wave run their
+// primitive tests together, once per round.
 RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax, const DrawKey& key, float& best_t, uint32_t& best_prim, int& best_side) {
-    bool found = false;
     const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
-    uint32_t i = 0;
+    Walk w; walk_init(w, tmax);
     const uint32_t n = S.n_bvh_nodes;
-    while (i < n) {
-        const rt_bvh_node N = S.bvh[i];
-        float x0 = fmaf(N.min[0], inv.x, -oi.x), x1 = fmaf(N.max[0], inv.x, -oi.x);
-        float y0 = fmaf(N.min[1], inv.y, -oi.y), y1 = fmaf(N.max[1], inv.y, -oi.y);
-        float z0 = fmaf(N.min[2], inv.z, -oi.z), z1 = fmaf(N.max[2], inv.z, -oi.z);
-        float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-        float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
-        if (!(tn <= tf)) { i = N.skip; continue; }
-        if (N.prim != RT_BVH_NONE) {
-            const uint32_t prim = N.prim & ~RT_BVH_EXACT;
-            bool enter = true;
-            if (N.prim & RT_BVH_EXACT) {
-                // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: true division of (bound - origin),
-                // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
-                float a0 = (N.min[0] - r.o.x) / r.d.x, a1 = (N.max[0] - r.o.x) / r.d.x;
-                float b0 = (N.min[1] - r.o.y) / r.d.y, b1 = (N.max[1] - r.o.y) / r.d.y;
-                float c0 = (N.min[2] - r.o.z) / r.d.z, c1 = (N.max[2] - r.o.z) / r.d.z;
-                float lo = tmin, hi = tmax;
-                lo = fmaxf(r.d.x < 0.0f ? a1 : a0, lo); hi = fminf(r.d.x < 0.0f ? a0 : a1, hi);
-                enter = !(hi <= lo);
-                lo = fmaxf(r.d.y < 0.0f ? b1 : b0, lo); hi = fminf(r.d.y < 0.0f ? b0 : b1, hi);
-                enter = enter && !(hi <= lo);
-                lo = fmaxf(r.d.z < 0.0f ? c1 : c0, lo); hi = fminf(r.d.z < 0.0f ? c0 : c1, hi);
-                enter = enter && !(hi <= lo);
-            }
-            float t; int side;
-            if (enter && prim_t(S, prim, r.o, r.d, tmin, tmax, r.time, key, t, side)) { tmax = t; best_t = t; best_prim = prim; best_side = side; found = true; }
-        }
-        ++i;
+    for (;;) {
+        uint32_t leaf = RT_BVH_NONE;
+        while (w.i < n && leaf == RT_BVH_NONE) leaf = walk_step(S, inv, oi, tmin, w);
+        if (leaf == RT_BVH_NONE) break;
+        walk_leaf(S, r, inv, tmin, key, leaf, w);
     }
-    return found;
+    best_t = w.t; best_prim = w.prim; best_side = w.side;
+    return w.found;
 }
 
 // ---------------------------------------------------------------- textures

@@ -79,15 +79,95 @@ __global__ void __launch_bounds__(RT_BS) k_raygen(PassParams P, RayQueue q, uint
     q.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 }
 
-__global__ void __launch_bounds__(RT_BS) k_traverse(SceneView S, PassParams P, RayQueue q, const uint32_t* count_ptr, uint2* hits, uint32_t bounce) {
+// BVH nodes staged into LDS: each workgroup copies the node array once per launch and every ray of the
+// launch walks it there.  The walk is a chain of dependent 32-byte node reads at a different address in
+// every lane; from the vector L1 that costs a cache-line lookup per lane per step, from LDS a banked read.
+// NODES_IN_LDS = false is the same kernel reading the nodes from global memory (trees too large for LDS).
+#define RT_TRAV_BS 1024
+template <bool NODES_IN_LDS>
+__device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds) {
+    SceneView V = S;
+    if (NODES_IN_LDS) {
+        const uint4* src = reinterpret_cast<const uint4*>(S.bvh);
+        for (uint32_t k = threadIdx.x; k < 2u * S.n_bvh_nodes; k += blockDim.x) lds[k] = src[k];
+        __syncthreads();
+        V.bvh = reinterpret_cast<const rt_bvh_node*>(lds);
+    }
+    return V;
+}
+
+// Closest hit for every ray of the queue: persistent waves with a flat per-lane state machine.
+//
+// A lane is either searching (stepping over BVH nodes), waiting on a leaf (its primitive test is due) or idle.
+// Each turn of the loop the wave either makes one node step for its searching lanes, or, once enough lanes
+// wait on a leaf (or nobody is searching), runs the primitive tests of all waiting lanes together; lanes whose
+// ray is finished take the next ray of the workgroup's share of the queue (one LDS atomic per wave and turn).
+// This keeps the long primitive tests from running for a handful of lanes at a time and keeps lanes busy
+// although rays need very different numbers of steps (20 to 200 on final_scene).
+// The per-ray arithmetic is walk_step / walk_leaf of rt_core.h, exactly what closest_hit() runs.
+#define RT_LEAF_BATCH 40  // run the primitive tests once this many of the 64 lanes wait on a leaf
+template <bool NODES_IN_LDS>
+__global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr, uint2* hits,
+                                                                                   uint32_t bounce) {
+    extern __shared__ uint4 lds_nodes[];
+    __shared__ uint32_t next_ray;
+    const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
     const uint32_t count = *count_ptr;
-    for (uint32_t i = blockIdx.x * RT_BS + threadIdx.x; i < count; i += gridDim.x * RT_BS) {
-        float4 a = q.od0[i], b = q.od1[i];
-        Ray r; r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
-        DrawKey key = make_key(P, __float_as_uint(b.w), bounce);
-        float t = 0.0f; uint32_t prim = 0; int side = 0;
-        bool hit = closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);  // lib.rs:90: (0.001, inf)
-        hits[i] = make_uint2(__float_as_uint(t), hit ? (prim | ((uint32_t)side << 29)) : RT_HIT_NONE);
+    const uint32_t begin = (uint32_t)((uint64_t)count * blockIdx.x / gridDim.x);
+    const uint32_t end = (uint32_t)((uint64_t)count * (blockIdx.x + 1) / gridDim.x);
+    if (threadIdx.x == 0) next_ray = begin;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_nodes = S.n_bvh_nodes;
+    const float tmin = 0.001f;  // lib.rs:90: (0.001, inf)
+
+    bool active = false, exhausted = false;
+    Ray r; r.o = v3(0, 0, 0); r.d = v3(1, 1, 1); r.time = 0.0f;
+    V3 inv = v3(1, 1, 1), oi = v3(0, 0, 0);
+    Walk w; walk_init(w, RT_INF_F);
+    uint32_t slot = 0, path = 0, leaf = RT_BVH_NONE;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle != 0ull && !exhausted) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&next_ray, n_idle);
+            base = __shfl(base, 0);
+            exhausted = base + n_idle >= end;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t mine = base + rank;
+            if (!active && mine < end) {
+                const float4 a = q.od0[mine], b = q.od1[mine];
+                r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
+                path = __float_as_uint(b.w);
+                inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+                walk_init(w, RT_INF_F);
+                slot = mine; leaf = RT_BVH_NONE;
+                active = n_nodes != 0;
+                if (!active) hits[slot] = make_uint2(0u, RT_HIT_NONE);
+            }
+        }
+        const unsigned long long act = __ballot(active);
+        if (act == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        const unsigned long long waiting = __ballot(active && leaf != RT_BVH_NONE);
+        const unsigned long long searching = act & ~waiting;
+        if (searching != 0ull && (uint32_t)__popcll(waiting) < RT_LEAF_BATCH) {
+            if (active && leaf == RT_BVH_NONE) leaf = walk_step(S, inv, oi, tmin, w);
+        } else {
+            if (active && leaf != RT_BVH_NONE) {
+                DrawKey key = make_key(P, path, bounce);
+                walk_leaf(S, r, inv, tmin, key, leaf, w);
+                leaf = RT_BVH_NONE;
+            }
+        }
+        if (active && leaf == RT_BVH_NONE && w.i >= n_nodes) {
+            hits[slot] = make_uint2(__float_as_uint(w.t), w.found ? (w.prim | ((uint32_t)w.side << 29)) : RT_HIT_NONE);
+            active = false;
+        }
     }
 }
 
@@ -135,11 +215,14 @@ __global__ void __launch_bounds__(RT_BS) k_shade(SceneView S, PassParams P, RayQ
 }
 
 // Every ray left in the queue runs the remaining iterations of ray_color in one launch.
-__global__ void __launch_bounds__(RT_BS) k_tail(SceneView S, PassParams P, RayQueue q, const uint32_t* count_ptr, float4* values, uint32_t* segment_counter,
-                                                uint32_t first_bounce) {
+template <bool NODES_IN_LDS>
+__global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_tail(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr, float4* values, uint32_t* segment_counter,
+                                                     uint32_t first_bounce) {
+    extern __shared__ uint4 lds_nodes[];
+    const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
     const uint32_t count = *count_ptr;
     uint32_t segments = 0;
-    for (uint32_t i = blockIdx.x * RT_BS + threadIdx.x; i < count; i += gridDim.x * RT_BS) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         float4 a = q.od0[i], b = q.od1[i], c = q.thr[i];
         Ray r; r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
         const uint32_t path = __float_as_uint(b.w);
@@ -243,6 +326,7 @@ struct rt_scene {
     SceneView view{};
     std::vector<void*> allocs;
     hipStream_t own_stream = nullptr;
+    bool lds_attr_set = false;
     // workspace
     uint64_t ws_paths = 0, ws_pixels = 0;
     RayQueue q[2]{};
@@ -400,7 +484,19 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     UP(images, D->images, D->n_images);
     UP(texels, D->texels, D->texel_bytes);
     UP(perm, D->perm_tables, 256u * (size_t)D->n_perm_tables);
-    UP(bvh, D->bvh, D->n_bvh_nodes);
+    {   // device copy of the node array, with RT_NODE_PLAIN_BOX set where the leaf's box is the primitive (see rt_core.h)
+        std::vector<rt_bvh_node> nodes(D->bvh, D->bvh + D->n_bvh_nodes);
+        for (rt_bvh_node& N : nodes) {
+            if (N.prim == RT_BVH_NONE || !(N.prim & RT_BVH_EXACT)) continue;
+            const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
+            if (Pp.geom != RT_GEOM_BOX || Pp.xf_count != 0 || (Pp.flags & RT_PRIM_MEDIUM)) continue;
+            const rt_box& B = D->boxes[Pp.geom_index];
+            bool same = true;
+            for (int c = 0; c < 3; ++c) same = same && B.min[c] == N.min[c] && B.max[c] == N.max[c];
+            if (same) N.prim |= RT_NODE_PLAIN_BOX;
+        }
+        UP(bvh, nodes.data(), nodes.size());
+    }
 #undef UP
     V.n_prims = D->n_prims; V.n_bvh_nodes = D->n_bvh_nodes;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
@@ -526,6 +622,14 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
     const uint32_t max_grid = (uint32_t)prop.multiProcessorCount * 8u;
+    // The node array goes to LDS when it fits beside nothing else (160 KB per CU, one 1024-thread workgroup per CU).
+    const size_t node_bytes = (size_t)sc->view.n_bvh_nodes * sizeof(rt_bvh_node);
+    const bool nodes_in_lds = node_bytes > 0 && node_bytes <= 144u * 1024u && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
+    if (nodes_in_lds && !sc->lds_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        sc->lds_attr_set = true;
+    }
     const uint32_t tail_threshold = (uint32_t)prop.multiProcessorCount * 512u;
     Launcher L{sc, stream, profile};
     hipEvent_t ev;
@@ -542,6 +646,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         P.sample_base = (uint32_t)s0; P.n_paths = ns * n_owned;
         const uint32_t grid_full = (P.n_paths + RT_BS - 1) / RT_BS;
         const uint32_t grid = std::min(grid_full, max_grid);
+        const uint32_t trav_grid = std::min((P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, (uint32_t)prop.multiProcessorCount);
         if ((st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
         hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, stream, P, sc->q[0], sc->counts, n_counts);
         if ((st = L.end(ev)) != RT_OK) return st;
@@ -555,7 +660,10 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         for (; b < depth; ++b) {
             if (tail_from >= 0 && !force_wavefront && (int)b >= tail_from) break;
             if ((st = L.begin(RT_K_TRAVERSE, &ev)) != RT_OK) return st;
-            hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->hits, b);
+            if (nodes_in_lds)
+                hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->hits, b);
+            else
+                hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->hits, b);
             if ((st = L.end(ev)) != RT_OK) return st;
             if ((st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
             hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->hits, sc->q[cur ^ 1], sc->counts + b,
@@ -573,7 +681,12 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         if (tail_from < 0 && !force_wavefront) tail_from = (int)depth;
         if (!finished && b < depth) {
             if ((st = L.begin(RT_K_TAIL, &ev)) != RT_OK) return st;
-            hipLaunchKernelGGL(k_tail, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->values, sc->counts + depth + 1, b);
+            if (nodes_in_lds)
+                hipLaunchKernelGGL(k_tail<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->values,
+                                   sc->counts + depth + 1, b);
+            else
+                hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->values,
+                                   sc->counts + depth + 1, b);
             if ((st = L.end(ev)) != RT_OK) return st;
             if (profile) {
                 HIP_TRY(hipMemcpyAsync(sc->h_counts, sc->counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

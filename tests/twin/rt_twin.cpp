@@ -8,6 +8,13 @@
 #include <thread>
 #include <vector>
 
+#include <cstdint>
+struct TwinCounters { unsigned long long nodes, leaves, prim_tests; uint32_t* trace; uint32_t trace_n, trace_cap; };
+static thread_local TwinCounters g_tc;
+static inline void twin_count_nodes() { g_tc.nodes++; }
+static inline void twin_count_leaves() { g_tc.leaves++; if (g_tc.trace && g_tc.trace_n < g_tc.trace_cap) g_tc.trace[g_tc.trace_n++] = (uint32_t)g_tc.nodes; }
+static inline void twin_count_prim_tests() { g_tc.prim_tests++; }
+#define RT_COUNT(name) twin_count_##name()
 #include "../../raytracing_amd/csrc/rt_core.h"
 
 using namespace rt;
@@ -69,6 +76,44 @@ void twin_material_scatter(const rt_scene_desc* D, const rt_hit* h, uint64_t see
     *scattered = sc.scattered ? 1 : 0;
     color[0] = sc.color.x; color[1] = sc.color.y; color[2] = sc.color.z;
     ray_o[0] = sc.o.x; ray_o[1] = sc.o.y; ray_o[2] = sc.o.z; ray_d[0] = sc.d.x; ray_d[1] = sc.d.y; ray_d[2] = sc.d.z;
+}
+
+// Per-ray traversal work (nodes visited, leaves reached, primitive tests run) for analysis.
+// trace (optional, n x trace_cap): the node-visit count at which each leaf was reached.
+void twin_traverse_stats(const rt_scene_desc* D, const rt_ray* rays, uint64_t n, uint64_t seed, uint32_t* out /* n x 3 */, uint32_t* trace, uint32_t trace_cap) {
+    SceneView S = view_of(D);
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r; r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]); r.time = rays[i].time;
+        DrawKey key; key.k0 = (uint32_t)seed; key.k1 = (uint32_t)(seed >> 32); key.pixel = (uint32_t)i; key.sample = 0; key.bounce = 0; key.medium_u = -1.0f;
+        g_tc = TwinCounters{0, 0, 0, trace ? trace + (size_t)i * trace_cap : nullptr, 0, trace_cap};
+        float t = 0; uint32_t prim = 0; int side = 0;
+        closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);
+        out[3 * i] = (uint32_t)g_tc.nodes; out[3 * i + 1] = (uint32_t)g_tc.leaves; out[3 * i + 2] = (uint32_t)g_tc.prim_tests;
+    }
+}
+
+// One camera path, bounce by bounce: out holds 12 floats per segment (origin, direction, t, prim or -1, throughput, value.x).
+// Returns the number of segments written.
+uint32_t twin_trace_sample(const rt_scene_desc* D, const rt_camera* cam, uint32_t width, uint32_t height, uint32_t i, uint32_t j, uint32_t sample, uint32_t depth,
+                           uint64_t seed, float* out, uint32_t cap) {
+    SceneView S = view_of(D);
+    Ray r = camera_ray(*cam, i, j, width, height, sample, (uint32_t)seed, (uint32_t)(seed >> 32));
+    V3 thr = v3(1, 1, 1), value = v3(0, 0, 0);
+    DrawKey key; key.k0 = (uint32_t)seed; key.k1 = (uint32_t)(seed >> 32); key.pixel = j * width + i; key.sample = sample; key.medium_u = -1.0f;
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < depth && n < cap; ++b) {
+        key.bounce = b;
+        float t = 0; uint32_t prim = 0; int side = 0;
+        float* o = out + 12 * n; ++n;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+        bool hit = closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);
+        o[6] = t; o[7] = hit ? (float)prim : -1.0f;
+        bool go = shade_step(S, r, thr, key, hit, t, prim, side, b + 1 >= depth, value);
+        o[8] = thr.x; o[9] = thr.y; o[10] = thr.z; o[11] = value.x;
+        if (!go) break;
+    }
+    return n;
 }
 
 float twin_perlin3(const uint8_t* perm256, float x, float y, float z) { return perlin3(perm256, v3(x, y, z)); }
