@@ -383,21 +383,26 @@ struct Ray {
 // reference's left-then-right order.  Node boxes are widened by the host, so the fp32 slab
 // test errs on the side of visiting.
 //
-// Bits of rt_bvh_node.prim on a leaf: the primitive id (RT_NODE_PRIM_MASK), RT_BVH_EXACT from the host,
-// and RT_NODE_PLAIN_BOX, which the library sets on its device copy for an exact leaf whose primitive is a
-// box without wrappers or medium: the leaf's own box then is the geometry and nothing else is fetched.
+// Bits of rt_bvh_node.prim on a leaf: the primitive id (RT_NODE_PRIM_MASK) and RT_BVH_EXACT from the host, plus two
+// that the library sets on its own device copy of the array (the arithmetic is the same with or without them; they
+// only say where the numbers are):
+//   RT_NODE_PLAIN_BOX     exact leaf whose primitive is a box without wrappers or medium: the leaf's box is the geometry;
+//   RT_NODE_PLAIN_SPHERE  leaf of a Sphere without wrappers or medium: the array slot after the leaf holds
+//                         {center.x, center.y, center.z, radius} as four doubles (the leaf's skip link jumps over it).
 #define RT_NODE_PRIM_MASK 0x1FFFFFFFu
 #define RT_NODE_PLAIN_BOX 0x40000000u
+#define RT_NODE_PLAIN_SPHERE 0x20000000u
 
 struct Walk {
     uint32_t i;     // next node to look at
+    uint32_t leaf_node;  // index of the node the last walk_step stood on
     float tmax;     // shrinking upper end of the ray interval
     float t;        // accepted hit so far
     uint32_t prim;
     int side;
     bool found;
 };
-RT_HD void walk_init(Walk& w, float tmax) { w.i = 0; w.tmax = tmax; w.t = 0.0f; w.prim = 0; w.side = 0; w.found = false; }
+RT_HD void walk_init(Walk& w, float tmax) { w.i = 0; w.leaf_node = 0; w.tmax = tmax; w.t = 0.0f; w.prim = 0; w.side = 0; w.found = false; }
 
 // One node step.  Returns the leaf's prim field when the ray now stands on a leaf whose primitive has to be
 // tried (w.i already points past it), RT_BVH_NONE otherwise.  Requires w.i < S.n_bvh_nodes.
@@ -410,44 +415,57 @@ RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w)
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), w.tmax));
     if (!(tn <= tf)) { w.i = N.skip; return RT_BVH_NONE; }
-    w.i += 1;
+    w.leaf_node = w.i;
+    w.i = (N.prim != RT_BVH_NONE) ? N.skip : w.i + 1;  // a leaf's skip link also jumps over its payload slot, if any
     return N.prim;
 }
 
-// The primitive test of the leaf at node w.i - 1: Object::scatter's intersect (lib.rs:284-285) behind the
-// leaf's own bounding-box test (lib.rs:236-240).
-RT_HD void walk_leaf(const SceneView& S, const Ray& r, V3 inv, float tmin, const DrawKey& key, uint32_t leaf, Walk& w) {
+// The primitive test of the leaf at node w.leaf_node: Object::scatter's intersect (lib.rs:284-285) behind the
+// leaf's own bounding-box test (lib.rs:236-240).  walk_leaf_fast handles the leaves that need nothing but the
+// node array (and no random draw) and returns false for the rest, which walk_leaf_generic takes.
+RT_HD void walk_accept(Walk& w, float t, uint32_t prim, int side) { w.tmax = t; w.t = t; w.prim = prim; w.side = side; w.found = true; }
+RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, uint32_t leaf, Walk& w) {
     const uint32_t prim = leaf & RT_NODE_PRIM_MASK;
-    RT_COUNT(leaves);
-    float t; int side;
-    if (leaf & RT_BVH_EXACT) {
-        // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: (bound - origin) over the direction,
-        // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
-        const rt_bvh_node N = S.bvh[w.i - 1];
-        float q[6];
-        box_quotients(N.min, N.max, r.o, inv, q);
-        float lo = tmin, hi = w.tmax;
-        lo = fmaxf(r.d.x < 0.0f ? q[1] : q[0], lo); hi = fminf(r.d.x < 0.0f ? q[0] : q[1], hi);
-        bool enter = !(hi <= lo);
-        lo = fmaxf(r.d.y < 0.0f ? q[3] : q[2], lo); hi = fminf(r.d.y < 0.0f ? q[2] : q[3], hi);
-        enter = enter && !(hi <= lo);
-        lo = fmaxf(r.d.z < 0.0f ? q[5] : q[4], lo); hi = fminf(r.d.z < 0.0f ? q[4] : q[5], hi);
-        enter = enter && !(hi <= lo);
-        if (!enter) return;
-        RT_COUNT(prim_tests);
-        bool plain = (leaf & RT_NODE_PLAIN_BOX) != 0;
-        if (!plain) {
-            const rt_prim P = S.prims[prim];
-            plain = P.geom == RT_GEOM_BOX && P.xf_count == 0 && !(P.flags & RT_PRIM_MEDIUM);
-        }
-        if (plain) {  // the leaf's box is the box: same arithmetic as box_t<float>, without fetching it
-            if (box_sides_q(N.min, N.max, r.o, r.d, q, tmin, w.tmax, t, side)) { w.tmax = t; w.t = t; w.prim = prim; w.side = side; w.found = true; }
-            return;
-        }
-    } else {
-        RT_COUNT(prim_tests);
+    if (leaf & RT_NODE_PLAIN_SPHERE) {
+        RT_COUNT(leaves); RT_COUNT(prim_tests);
+        const double* c = reinterpret_cast<const double*>(&S.bvh[w.leaf_node + 1]);
+        rt_sphere sp;
+        sp.center[0] = c[0]; sp.center[1] = c[1]; sp.center[2] = c[2]; sp.radius = c[3];
+        double t64;
+        if (sphere_root(sp, false, d3(r.o), d3(r.d), r.time, t64) && t64 > (double)tmin && t64 < (double)w.tmax) walk_accept(w, (float)t64, prim, 0);
+        return true;
     }
-    if (prim_t(S, prim, r.o, r.d, tmin, w.tmax, r.time, key, t, side)) { w.tmax = t; w.t = t; w.prim = prim; w.side = side; w.found = true; }
+    if (!(leaf & RT_BVH_EXACT)) return false;
+    // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: (bound - origin) over the direction,
+    // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
+    const rt_bvh_node N = S.bvh[w.leaf_node];
+    float q[6];
+    box_quotients(N.min, N.max, r.o, inv, q);
+    float lo = tmin, hi = w.tmax;
+    lo = fmaxf(r.d.x < 0.0f ? q[1] : q[0], lo); hi = fminf(r.d.x < 0.0f ? q[0] : q[1], hi);
+    bool enter = !(hi <= lo);
+    lo = fmaxf(r.d.y < 0.0f ? q[3] : q[2], lo); hi = fminf(r.d.y < 0.0f ? q[2] : q[3], hi);
+    enter = enter && !(hi <= lo);
+    lo = fmaxf(r.d.z < 0.0f ? q[5] : q[4], lo); hi = fminf(r.d.z < 0.0f ? q[4] : q[5], hi);
+    enter = enter && !(hi <= lo);
+    if (!enter) { RT_COUNT(leaves); return true; }
+    bool plain = (leaf & RT_NODE_PLAIN_BOX) != 0;
+    if (!plain) {
+        const rt_prim P = S.prims[prim];
+        plain = P.geom == RT_GEOM_BOX && P.xf_count == 0 && !(P.flags & RT_PRIM_MEDIUM);
+    }
+    if (!plain) return false;
+    RT_COUNT(leaves); RT_COUNT(prim_tests);
+    float t; int side;  // the leaf's box is the box: same arithmetic as box_t<float>, without fetching it
+    if (box_sides_q(N.min, N.max, r.o, r.d, q, tmin, w.tmax, t, side)) walk_accept(w, t, prim, side);
+    return true;
+}
+// Everything else: the general Intersection::intersect.  (An exact leaf arrives here only after walk_leaf_fast
+// has let the ray into its box.)
+RT_HD void walk_leaf_generic(const SceneView& S, const Ray& r, float tmin, const DrawKey& key, uint32_t leaf, Walk& w) {
+    RT_COUNT(leaves); RT_COUNT(prim_tests);
+    float t; int side;
+    if (prim_t(S, leaf & RT_NODE_PRIM_MASK, r.o, r.d, tmin, w.tmax, r.time, key, t, side)) walk_accept(w, t, leaf & RT_NODE_PRIM_MASK, side);
 }
 
 // The whole walk for one ray.  Two nested loops on purpose: the inner loop only steps over nodes until it
@@ -462,7 +480,7 @@ RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax,
         uint32_t leaf = RT_BVH_NONE;
         while (w.i < n && leaf == RT_BVH_NONE) leaf = walk_step(S, inv, oi, tmin, w);
         if (leaf == RT_BVH_NONE) break;
-        walk_leaf(S, r, inv, tmin, key, leaf, w);
+        if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, key, leaf, w);
     }
     best_t = w.t; best_prim = w.prim; best_side = w.side;
     return w.found;

@@ -105,7 +105,15 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 // This keeps the long primitive tests from running for a handful of lanes at a time and keeps lanes busy
 // although rays need very different numbers of steps (20 to 200 on final_scene).
 // The per-ray arithmetic is walk_step / walk_leaf of rt_core.h, exactly what closest_hit() runs.
-#define RT_LEAF_BATCH 40  // run the primitive tests once this many of the 64 lanes wait on a leaf
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 40      // run the primitive tests once this many of the 64 lanes wait on a leaf
+#endif
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 12      // fetch new rays once this many lanes are idle (a fetch waits on global memory)
+#endif
+#ifndef RT_STEPS_PER_TURN
+#define RT_STEPS_PER_TURN 4   // node steps between two looks at the wave's state
+#endif
 template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr, uint2* hits,
                                                                                    uint32_t bounce) {
@@ -128,8 +136,8 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
     uint32_t slot = 0, path = 0, leaf = RT_BVH_NONE;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
-        if (idle != 0ull && !exhausted) {
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!exhausted && (n_idle >= RT_REFILL_MIN)) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&next_ray, n_idle);
             base = __shfl(base, 0);
@@ -156,11 +164,12 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
         const unsigned long long waiting = __ballot(active && leaf != RT_BVH_NONE);
         const unsigned long long searching = act & ~waiting;
         if (searching != 0ull && (uint32_t)__popcll(waiting) < RT_LEAF_BATCH) {
-            if (active && leaf == RT_BVH_NONE) leaf = walk_step(S, inv, oi, tmin, w);
+#pragma unroll
+            for (int k = 0; k < RT_STEPS_PER_TURN; ++k)
+                if (active && leaf == RT_BVH_NONE && w.i < n_nodes) leaf = walk_step(S, inv, oi, tmin, w);
         } else {
             if (active && leaf != RT_BVH_NONE) {
-                DrawKey key = make_key(P, path, bounce);
-                walk_leaf(S, r, inv, tmin, key, leaf, w);
+                if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, make_key(P, path, bounce), leaf, w);
                 leaf = RT_BVH_NONE;
             }
         }
@@ -484,21 +493,42 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     UP(images, D->images, D->n_images);
     UP(texels, D->texels, D->texel_bytes);
     UP(perm, D->perm_tables, 256u * (size_t)D->n_perm_tables);
-    {   // device copy of the node array, with RT_NODE_PLAIN_BOX set where the leaf's box is the primitive (see rt_core.h)
-        std::vector<rt_bvh_node> nodes(D->bvh, D->bvh + D->n_bvh_nodes);
-        for (rt_bvh_node& N : nodes) {
-            if (N.prim == RT_BVH_NONE || !(N.prim & RT_BVH_EXACT)) continue;
+    {   // device copy of the node array with the leaf annotations and payload slots of rt_core.h
+        std::vector<uint32_t> new_index(D->n_bvh_nodes + 1);
+        auto plain_sphere = [&](const rt_bvh_node& N) {
+            if (N.prim == RT_BVH_NONE) return false;
             const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
-            if (Pp.geom != RT_GEOM_BOX || Pp.xf_count != 0 || (Pp.flags & RT_PRIM_MEDIUM)) continue;
-            const rt_box& B = D->boxes[Pp.geom_index];
-            bool same = true;
-            for (int c = 0; c < 3; ++c) same = same && B.min[c] == N.min[c] && B.max[c] == N.max[c];
-            if (same) N.prim |= RT_NODE_PLAIN_BOX;
+            return Pp.geom == RT_GEOM_SPHERE && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM);
+        };
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) { new_index[i] = at; at += plain_sphere(D->bvh[i]) ? 2u : 1u; }
+        new_index[D->n_bvh_nodes] = at;
+        std::vector<rt_bvh_node> nodes(at);
+        for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) {
+            rt_bvh_node N = D->bvh[i];
+            N.skip = new_index[N.skip];
+            if (N.prim != RT_BVH_NONE) {
+                const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
+                if (plain_sphere(N)) {
+                    N.prim |= RT_NODE_PLAIN_SPHERE;
+                    const rt_sphere& sp = D->spheres[Pp.geom_index];
+                    const double payload[4] = {sp.center[0], sp.center[1], sp.center[2], sp.radius};
+                    static_assert(sizeof(payload) == sizeof(rt_bvh_node), "payload slot size");
+                    std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
+                } else if ((N.prim & RT_BVH_EXACT) && Pp.geom == RT_GEOM_BOX && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM)) {
+                    const rt_box& B = D->boxes[Pp.geom_index];
+                    bool same = true;
+                    for (int c = 0; c < 3; ++c) same = same && B.min[c] == N.min[c] && B.max[c] == N.max[c];
+                    if (same) N.prim |= RT_NODE_PLAIN_BOX;
+                }
+            }
+            nodes[new_index[i]] = N;
         }
         UP(bvh, nodes.data(), nodes.size());
+        V.n_bvh_nodes = (uint32_t)nodes.size();
     }
 #undef UP
-    V.n_prims = D->n_prims; V.n_bvh_nodes = D->n_bvh_nodes;
+    V.n_prims = D->n_prims;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
