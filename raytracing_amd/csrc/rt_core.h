@@ -35,6 +35,7 @@ namespace rt {
 #define RT_PI_F 3.14159265358979323846f
 #define RT_PI_D 3.14159265358979323846
 #define RT_INF_F (__builtin_inff())
+#define RT_NAN_F (__builtin_nanf(""))
 #define RT_TAG_CAMERA 0xFFFFFFFFu
 
 struct V3 { float x, y, z; };
@@ -308,7 +309,7 @@ struct Hit {  // IntersectionPoint (shape.rs:539-550)
 // Point, normal and surface coordinates in the shape's frame for an accepted (t, side).  Runs once per
 // path segment (not per candidate), in f64: the ray parameter is re-derived in f64 (t is its fp32
 // rounding), so the point is the reference's point rounded once rather than origin + fp32(t) * direction.
-RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float time, float t, int side, D3& pt, D3& n, double& u, double& v) {
+RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float time, float t, int side, bool want_uv, D3& pt, D3& n, double& u, double& v) {
     u = 0.0; v = 0.0;
     if (P.flags & RT_PRIM_MEDIUM) {
         pt = ray_at(o, d, (double)t);
@@ -322,13 +323,15 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
         D3 p = ray_at(o, d, t64);
         D3 pc = p - c;
         n = pc * (1.0 / sqrt(dot(pc, pc)));
-        D3 q = pc * (1.0 / sp.radius);  // shape.rs:275 divides by the signed radius
-        float phi = atan2f((float)q.z, (float)q.x);
-        // theta = asin(q.y) as atan2(q.y, sqrt(1 - q.y^2)), the square root in f64: exact for every |q.y| <= 1,
-        // NaN beyond like asin, and without fp32 asin's loss of accuracy near the poles
-        float theta = atan2f((float)q.y, (float)sqrt(1.0 - q.y * q.y));
-        u = (double)(1.0f - (phi + RT_PI_F) / (2.0f * RT_PI_F));
-        v = (double)((theta + RT_PI_F / 2.0f) / RT_PI_F);
+        if (want_uv) {
+            D3 q = pc * (1.0 / sp.radius);  // shape.rs:275 divides by the signed radius
+            float phi = atan2f((float)q.z, (float)q.x);
+            // theta = asin(q.y) as atan2(q.y, sqrt(1 - q.y^2)), the square root in f64: exact for every |q.y| <= 1,
+            // NaN beyond like asin, and without fp32 asin's loss of accuracy near the poles
+            float theta = atan2f((float)q.y, (float)sqrt(1.0 - q.y * q.y));
+            u = (double)(1.0f - (phi + RT_PI_F) / (2.0f * RT_PI_F));
+            v = (double)((theta + RT_PI_F / 2.0f) / RT_PI_F);
+        }
         pt = p;
     } else {
         uint32_t axis; float x0, y0, x1, y1, hgt; bool flip_side = false;
@@ -342,8 +345,10 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
         const double t64 = ((double)hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321
         pt = ray_at(o, d, t64);
-        u = (compd(pt, p1) - (double)x0) / ((double)x1 - (double)x0);
-        v = (compd(pt, p2) - (double)y0) / ((double)y1 - (double)y0);
+        if (want_uv) {
+            u = (compd(pt, p1) - (double)x0) / ((double)x1 - (double)x0);
+            v = (compd(pt, p2) - (double)y0) / ((double)y1 - (double)y0);
+        }
         const double s = flip_side ? -1.0 : 1.0;
         n = d3(oo == 0 ? s : 0.0, oo == 1 ? s : 0.0, oo == 2 ? s : 0.0);
     }
@@ -352,13 +357,14 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
 // The rest of the IntersectionPoint for an accepted (prim, t, side), carried back out through the
 // wrappers (Rotated rotates point / normal / in_vec by +angle, shape.rs:378-383; Translated adds the
 // offset to the point, shape.rs:364-367).
-RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float time, float t, int side, Hit& h) {
-    const rt_prim P = S.prims[prim];
-    h.t = t; h.in_vec = normed(d); h.prim = prim;
+// want_uv / want_in_vec = false leave (u, v) = (0, 0) / in_vec unset for callers that know the material reads neither.
+RT_HD void prim_surface(const SceneView& S, const rt_prim& P, uint32_t prim, V3 o, V3 d, float time, float t, int side, bool want_uv, bool want_in_vec, Hit& h) {
+    h.t = t; h.prim = prim;
+    h.in_vec = want_in_vec ? normed(d) : d;
     D3 lo = d3(o), ld = d3(d);
     to_local(S, P, lo, ld);
     D3 pt, n; double u, v;
-    local_surface(S, P, lo, ld, time, t, side, pt, n, u, v);
+    local_surface(S, P, lo, ld, time, t, side, want_uv, pt, n, u, v);
     // a medium's hit lives in the frame of the ConstantMedium wrapper: the inner wrappers move only the point
     const uint32_t n_from = (P.flags & RT_PRIM_MEDIUM) ? P.xf_outer : P.xf_count;
     for (uint32_t k = P.xf_count; k > 0; --k) {
@@ -368,6 +374,9 @@ RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float tim
     }
     if (P.flags & RT_PRIM_FLIP) n = n * -1.0;
     h.point = v3(pt); h.normal = v3(n); h.u = (float)u; h.v = (float)v;
+}
+RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float time, float t, int side, Hit& h) {
+    prim_surface(S, S.prims[prim], prim, o, d, time, t, side, true, true, h);
 }
 
 // --------------------------------------------------------------- traversal
@@ -579,8 +588,7 @@ RT_HD float schlick(float cosine, float ri) {  // materials.rs:143
 struct Scatter { bool scattered; V3 color; V3 o, d; };  // RayHit (lib.rs:300-306)
 
 // Material::scatter (materials.rs:28-114) with the draws of stream 0 of the segment.
-RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& key) {
-    const rt_material M = S.materials[S.prims[h.prim].material];
+RT_HD Scatter material_scatter(const SceneView& S, const rt_material& M, const Hit& h, const DrawKey& key) {
     const U4 rnd = philox4x32_10(key.pixel, key.sample, key.bounce, 0u, key.k0, key.k1);
     Scatter out;
     out.o = h.point;
@@ -591,9 +599,10 @@ RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& 
         // nearly opposite to the normal, so it is formed in f64 like the reference's.
         D3 nd = d3(h.normal);
         D3 dir = random_unit_vector_d(u01(rnd.x), u01(rnd.y)) + nd;
-        double cosine = dot(nd, dir) / sqrt(dot(dir, dir));
-        double pdf = fmax(cosine / RT_PI_D, 0.0);
-        float w = (float)((pdf * RT_PI_D) / cosine);
+        // weight = max(cos / pi, 0) * pi / cos, in the reference's f64 and rounded to fp32: 1 for cos > 0 (the quotient is
+        // within an f64 ulp of 1), 0 for cos < 0, NaN for cos = 0; the sign of cos is the sign of normal . direction
+        double proj = dot(nd, dir);
+        float w = proj > 0.0 ? 1.0f : (proj < 0.0 ? -0.0f : RT_NAN_F);
         V3 tex = texture_color(S, M.texture, h.u, h.v, h.point);
         out.color = tex * w;
         out.scattered = true; out.d = v3(dir);
@@ -620,6 +629,13 @@ RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& 
     }
     return out;
 }
+RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& key) {
+    return material_scatter(S, S.materials[S.prims[h.prim].material], h, key);
+}
+
+// Bit of rt_material.reserved[0] that the library sets on its own copy of the materials: no texture this material
+// can reach reads the surface coordinates (u, v), so shading need not compute them.
+#define RT_MAT_SKIP_UV 1u
 
 // One step of ray_color (lib.rs:89-101) for a ray whose closest hit is known.
 // Returns true when the path continues (r and thr updated); otherwise `value` is the
@@ -627,8 +643,10 @@ RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& 
 RT_HD bool shade_step(const SceneView& S, Ray& r, V3& thr, const DrawKey& key, bool hit, float t, uint32_t prim, int side, bool last_bounce, V3& value) {
     if (!hit) { value = thr * v3(S.background[0], S.background[1], S.background[2]); return false; }  // lib.rs:91
     Hit h;
-    prim_surface(S, prim, r.o, r.d, r.time, t, side, h);
-    Scatter sc = material_scatter(S, h, key);
+    const rt_prim P = S.prims[prim];
+    const rt_material M = S.materials[P.material];
+    prim_surface(S, P, prim, r.o, r.d, r.time, t, side, !(M.reserved[0] & RT_MAT_SKIP_UV), M.kind == RT_MAT_METAL || M.kind == RT_MAT_DIELECTRIC, h);
+    Scatter sc = material_scatter(S, M, h, key);
     if (!sc.scattered) { value = thr * sc.color; return false; }  // lib.rs:92
     thr = thr * sc.color;
     r.o = sc.o; r.d = sc.d;

@@ -40,13 +40,14 @@ using namespace rt;
 struct RayQueue {
     float4* od0;  // o.x o.y o.z d.x
     float4* od1;  // d.y d.z time path(bits)
-    float4* thr;  // throughput rgb, unused
+    float4* thr;  // throughput rgb, pixel(bits): the pixel's number j * width + i in the frame
 };
 
 struct PassParams {
     rt_camera cam;
     uint32_t width, height;
     uint32_t n_owned;      // pixels owned by this rank
+    uint64_t owned_magic;  // floor(2^64 / n_owned) + 1 (0 when n_owned == 1): path / n_owned as a multiply-high
     uint32_t n_paths;      // n_owned * samples in this pass
     uint32_t sample_base;  // first sample index of the pass
     uint32_t k0, k1;       // seed
@@ -54,11 +55,15 @@ struct PassParams {
     const uint32_t* owned; // global pixel id (j * width + i) of every owned pixel
 };
 
-__device__ __forceinline__ DrawKey make_key(const PassParams& P, uint32_t path, uint32_t bounce) {
+// Path p of a pass is sample sample_base + p / n_owned of owned pixel p % n_owned.
+__device__ __forceinline__ uint32_t path_sample(const PassParams& P, uint32_t path) {
+    return P.sample_base + (P.owned_magic ? (uint32_t)__umul64hi((uint64_t)path, P.owned_magic) : path);
+}
+__device__ __forceinline__ DrawKey make_key(const PassParams& P, uint32_t path, uint32_t pixel, uint32_t bounce) {
     DrawKey k;
     k.k0 = P.k0; k.k1 = P.k1;
-    k.pixel = P.owned[path % P.n_owned];
-    k.sample = P.sample_base + path / P.n_owned;
+    k.pixel = pixel;
+    k.sample = path_sample(P, path);
     k.bounce = bounce;
     k.medium_u = -1.0f;
     return k;
@@ -71,12 +76,12 @@ __global__ void __launch_bounds__(RT_BS) k_raygen(PassParams P, RayQueue q, uint
         for (uint32_t i = 1; i < n_counts; ++i) counts[i] = 0;
     }
     if (p >= P.n_paths) return;
-    uint32_t pixel = P.owned[p % P.n_owned];
-    uint32_t sample = P.sample_base + p / P.n_owned;
+    const uint32_t sample = path_sample(P, p);
+    const uint32_t pixel = P.owned[p - (sample - P.sample_base) * P.n_owned];
     Ray r = camera_ray(P.cam, pixel % P.width, pixel / P.width, P.width, P.height, sample, P.k0, P.k1);
     q.od0[p] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
     q.od1[p] = make_float4(r.d.y, r.d.z, r.time, __uint_as_float(p));
-    q.thr[p] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    q.thr[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
 }
 
 // BVH nodes staged into LDS: each workgroup copies the node array once per launch and every ray of the
@@ -111,29 +116,36 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 12      // fetch new rays once this many lanes are idle (a fetch waits on global memory)
 #endif
+#define RT_TRAV_GROUP 256u    // rays dealt to a workgroup at a time
 #ifndef RT_STEPS_PER_TURN
 #define RT_STEPS_PER_TURN 4   // node steps between two looks at the wave's state
 #endif
 template <bool NODES_IN_LDS>
-__global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr, uint2* hits,
-                                                                                   uint32_t bounce) {
+__global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
+                                                                                   uint2* hits, uint32_t bounce) {
     extern __shared__ uint4 lds_nodes[];
     __shared__ uint32_t next_ray;
     const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
     const uint32_t count = *count_ptr;
-    const uint32_t begin = (uint32_t)((uint64_t)count * blockIdx.x / gridDim.x);
-    const uint32_t end = (uint32_t)((uint64_t)count * (blockIdx.x + 1) / gridDim.x);
-    if (threadIdx.x == 0) next_ray = begin;
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_nodes = S.n_bvh_nodes;
     const float tmin = 0.001f;  // lib.rs:90: (0.001, inf)
+    // The queue is dealt out to the workgroups in groups of RT_TRAV_GROUP rays, round robin, so that every workgroup
+    // gets an even sample of the queue whatever order it is in; inside a workgroup the waves draw from the workgroup's
+    // rays through one LDS counter.  Local ray number L is ray ((L / G) * gridDim + blockIdx) * G + L % G of the queue.
+    const uint32_t n_groups = (count + RT_TRAV_GROUP - 1) / RT_TRAV_GROUP;
+    const uint32_t my_groups = n_groups > blockIdx.x ? (n_groups - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const uint32_t my_rays = my_groups * RT_TRAV_GROUP;
+    if (threadIdx.x == 0) next_ray = 0;
+    __syncthreads();
 
-    bool active = false, exhausted = false;
+    bool active = false, exhausted = n_nodes == 0;
     Ray r; r.o = v3(0, 0, 0); r.d = v3(1, 1, 1); r.time = 0.0f;
     V3 inv = v3(1, 1, 1), oi = v3(0, 0, 0);
     Walk w; walk_init(w, RT_INF_F);
-    uint32_t slot = 0, path = 0, leaf = RT_BVH_NONE;
+    uint32_t slot = 0, path = 0, pixel = 0, leaf = RT_BVH_NONE;
+    if (n_nodes == 0)  // nothing to hit: every ray misses
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) hits[i] = make_uint2(0u, RT_HIT_NONE);
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -141,19 +153,19 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&next_ray, n_idle);
             base = __shfl(base, 0);
-            exhausted = base + n_idle >= end;
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const uint32_t mine = base + rank;
-            if (!active && mine < end) {
+            exhausted = base + n_idle >= my_rays;
+            const uint32_t local = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t mine = ((local / RT_TRAV_GROUP) * gridDim.x + blockIdx.x) * RT_TRAV_GROUP + local % RT_TRAV_GROUP;
+            if (!active && local < my_rays && mine < count) {
                 const float4 a = q.od0[mine], b = q.od1[mine];
                 r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
                 path = __float_as_uint(b.w);
+                pixel = __float_as_uint(q.thr[mine].w);
                 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
                 walk_init(w, RT_INF_F);
                 slot = mine; leaf = RT_BVH_NONE;
-                active = n_nodes != 0;
-                if (!active) hits[slot] = make_uint2(0u, RT_HIT_NONE);
+                active = true;
             }
         }
         const unsigned long long act = __ballot(active);
@@ -169,7 +181,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
                 if (active && leaf == RT_BVH_NONE && w.i < n_nodes) leaf = walk_step(S, inv, oi, tmin, w);
         } else {
             if (active && leaf != RT_BVH_NONE) {
-                if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, make_key(P, path, bounce), leaf, w);
+                if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, make_key(P, path, pixel, bounce), leaf, w);
                 leaf = RT_BVH_NONE;
             }
         }
@@ -189,14 +201,15 @@ __global__ void __launch_bounds__(RT_BS) k_shade(SceneView S, PassParams P, RayQ
     for (uint32_t base = blockIdx.x * RT_BS; base < count; base += gridDim.x * RT_BS) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false;
-        Ray r; V3 thr; uint32_t path = 0;
+        Ray r; V3 thr; uint32_t path = 0, pixel = 0;
         if (i < count) {
             float4 a = qin.od0[i], b = qin.od1[i], c = qin.thr[i];
             uint2 hh = hits[i];
             r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
             path = __float_as_uint(b.w);
             thr = v3(c.x, c.y, c.z);
-            DrawKey key = make_key(P, path, bounce);
+            pixel = __float_as_uint(c.w);
+            DrawKey key = make_key(P, path, pixel, bounce);
             V3 value;
             bool hit = hh.y != RT_HIT_NONE;
             alive = shade_step(S, r, thr, key, hit, __uint_as_float(hh.x), hh.y & 0x1FFFFFFFu, (int)(hh.y >> 29), bounce + 1 >= P.max_depth, value);
@@ -217,7 +230,7 @@ __global__ void __launch_bounds__(RT_BS) k_shade(SceneView S, PassParams P, RayQ
             const uint32_t slot = block_base + wave_cnt[wave] + prefix;
             qout.od0[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
             qout.od1[slot] = make_float4(r.d.y, r.d.z, r.time, __uint_as_float(path));
-            qout.thr[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+            qout.thr[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
         }
         __syncthreads();
     }
@@ -237,7 +250,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_tail(Scen
         const uint32_t path = __float_as_uint(b.w);
         V3 thr = v3(c.x, c.y, c.z);
         V3 value = v3(0.0f, 0.0f, 0.0f);
-        DrawKey key = make_key(P, path, first_bounce);
+        DrawKey key = make_key(P, path, __float_as_uint(c.w), first_bounce);
         for (uint32_t bounce = first_bounce; bounce < P.max_depth; ++bounce) {
             key.bounce = bounce;
             ++segments;
@@ -488,7 +501,26 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     UP(rects, D->rects, D->n_rects);
     UP(boxes, D->boxes, D->n_boxes);
     UP(xforms, D->xforms, D->n_xforms);
-    UP(materials, D->materials, D->n_materials);
+    {   // materials, with RT_MAT_SKIP_UV where no reachable texture is an image (the only kind that reads (u, v))
+        std::vector<rt_material> mats(D->materials, D->materials + D->n_materials);
+        for (auto& M : mats) {
+            bool reads_uv = false;
+            if (M.kind == RT_MAT_LAMBERTIAN || M.kind == RT_MAT_DIFFUSE_LIGHT || M.kind == RT_MAT_ISOTROPIC) {
+                std::vector<uint32_t> todo{M.texture};
+                for (uint32_t depth = 0; depth <= RT_MAX_TEXTURE_NESTING && !todo.empty() && !reads_uv; ++depth) {
+                    std::vector<uint32_t> next;
+                    for (uint32_t t : todo) {
+                        const rt_texture& T = D->textures[t];
+                        if (T.kind == RT_TEX_IMAGE) reads_uv = true;
+                        else if (T.kind == RT_TEX_CHECKERED) { next.push_back(T.odd); next.push_back(T.even); }
+                    }
+                    todo.swap(next);
+                }
+            }
+            if (reads_uv) M.reserved[0] &= ~RT_MAT_SKIP_UV; else M.reserved[0] |= RT_MAT_SKIP_UV;
+        }
+        UP(materials, mats.data(), mats.size());
+    }
     UP(textures, D->textures, D->n_textures);
     UP(images, D->images, D->n_images);
     UP(texels, D->texels, D->texel_bytes);
@@ -666,6 +698,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
 
     PassParams P;
     P.cam = *cam; P.width = W; P.height = H; P.n_owned = n_owned;
+    P.owned_magic = n_owned > 1 ? ~0ull / n_owned + 1 : 0;
     P.k0 = (uint32_t)ro->seed; P.k1 = (uint32_t)(ro->seed >> 32); P.max_depth = depth; P.owned = sc->owned;
 
     const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;

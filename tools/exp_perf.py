@@ -1,11 +1,10 @@
-import sys, time, os, shutil
-sys.path.insert(0, '.')
-lib = sys.argv[1]
-import raytracing_amd._abi as _abi
-if lib != 'base':
-    _abi.HIP_LIB_PATH = os.path.join(os.path.dirname(_abi.HIP_LIB_PATH), lib)
+"""Experiment: per-launch kernel times of one 16-spp pass of final_scene 800x800 (RT_DUMP_LAUNCHES=1)."""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import raytracing_amd as rt
 sc, co = rt.Scene.example('final_scene', 1, rt.earthmap()); cam = rt.Camera(co)
-sc.render(cam, rt.ImageOptions(800, 800, 16, 50), rt.RenderOptions(seed=1))
-sc.render(cam, rt.ImageOptions(800, 800, 64, 50), rt.RenderOptions(seed=1, flags=1)); p = sc.profile()
-print(lib, 'traverse_ms', round(p['traverse_ms'], 1), 'shade_ms', round(p['shade_ms'], 1), flush=True)
+io = rt.ImageOptions(800, 800, 16, 50)
+sc.render(cam, io, rt.RenderOptions(seed=1))
+sc.render(cam, io, rt.RenderOptions(seed=1, flags=1 | 2))
+p = sc.profile()
+print({k: round(v, 2) for k, v in p.items() if k.endswith('_ms')})
