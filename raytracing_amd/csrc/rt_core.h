@@ -309,30 +309,34 @@ struct Hit {  // IntersectionPoint (shape.rs:539-550)
 // Point, normal and surface coordinates in the shape's frame for an accepted (t, side).  Runs once per
 // path segment (not per candidate), in f64: the ray parameter is re-derived in f64 (t is its fp32
 // rounding), so the point is the reference's point rounded once rather than origin + fp32(t) * direction.
-RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float time, float t, int side, bool want_uv, D3& pt, D3& n, double& u, double& v) {
-    u = 0.0; v = 0.0;
+RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float time, float t, int side, bool want_uv, D3& pt_out, D3& n_out, double& u, double& v) {
+    // (every branch writes the same scalar locals and the results are put together once at the end: stores to
+    // different fields of the caller's structs in different branches end up in scratch memory)
+    double px, py, pz, nx, ny, nz, uu = 0.0, vv = 0.0;
     if (P.flags & RT_PRIM_MEDIUM) {
-        pt = ray_at(o, d, (double)t);
-        n = d3(1.0, 0.0, 0.0);  // shape.rs:413
+        const D3 p = ray_at(o, d, (double)t);
+        px = p.x; py = p.y; pz = p.z;
+        nx = 1.0; ny = 0.0; nz = 0.0;  // shape.rs:413
     } else if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
         const rt_sphere sp = S.spheres[P.geom_index];
         const bool moving = P.geom == RT_GEOM_MOVING_SPHERE;
         double t64 = (double)t;
         sphere_root(sp, moving, o, d, time, t64);
-        D3 c = sphere_center(sp, moving, time);
-        D3 p = ray_at(o, d, t64);
-        D3 pc = p - c;
-        n = pc * (1.0 / sqrt(dot(pc, pc)));
+        const D3 c = sphere_center(sp, moving, time);
+        const D3 p = ray_at(o, d, t64);
+        const D3 pc = p - c;
+        const double inv_len = 1.0 / sqrt(dot(pc, pc));
+        nx = pc.x * inv_len; ny = pc.y * inv_len; nz = pc.z * inv_len;
         if (want_uv) {
-            D3 q = pc * (1.0 / sp.radius);  // shape.rs:275 divides by the signed radius
-            float phi = atan2f((float)q.z, (float)q.x);
+            const D3 q = pc * (1.0 / sp.radius);  // shape.rs:275 divides by the signed radius
+            const float phi = atan2f((float)q.z, (float)q.x);
             // theta = asin(q.y) as atan2(q.y, sqrt(1 - q.y^2)), the square root in f64: exact for every |q.y| <= 1,
             // NaN beyond like asin, and without fp32 asin's loss of accuracy near the poles
-            float theta = atan2f((float)q.y, (float)sqrt(1.0 - q.y * q.y));
-            u = (double)(1.0f - (phi + RT_PI_F) / (2.0f * RT_PI_F));
-            v = (double)((theta + RT_PI_F / 2.0f) / RT_PI_F);
+            const float theta = atan2f((float)q.y, (float)sqrt(1.0 - q.y * q.y));
+            uu = (double)(1.0f - (phi + RT_PI_F) / (2.0f * RT_PI_F));
+            vv = (double)((theta + RT_PI_F / 2.0f) / RT_PI_F);
         }
-        pt = p;
+        px = p.x; py = p.y; pz = p.z;
     } else {
         uint32_t axis; float x0, y0, x1, y1, hgt; bool flip_side = false;
         if (P.geom == RT_GEOM_RECT) {
@@ -344,14 +348,16 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
         }
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
         const double t64 = ((double)hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321
-        pt = ray_at(o, d, t64);
+        const D3 p = ray_at(o, d, t64);
         if (want_uv) {
-            u = (compd(pt, p1) - (double)x0) / ((double)x1 - (double)x0);
-            v = (compd(pt, p2) - (double)y0) / ((double)y1 - (double)y0);
+            uu = (compd(p, p1) - (double)x0) / ((double)x1 - (double)x0);
+            vv = (compd(p, p2) - (double)y0) / ((double)y1 - (double)y0);
         }
         const double s = flip_side ? -1.0 : 1.0;
-        n = d3(oo == 0 ? s : 0.0, oo == 1 ? s : 0.0, oo == 2 ? s : 0.0);
+        px = p.x; py = p.y; pz = p.z;
+        nx = oo == 0 ? s : 0.0; ny = oo == 1 ? s : 0.0; nz = oo == 2 ? s : 0.0;
     }
+    pt_out = d3(px, py, pz); n_out = d3(nx, ny, nz); u = uu; v = vv;
 }
 
 // The rest of the IntersectionPoint for an accepted (prim, t, side), carried back out through the

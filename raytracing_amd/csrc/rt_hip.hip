@@ -192,13 +192,17 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
     }
 }
 
-__global__ void __launch_bounds__(RT_BS) k_shade(SceneView S, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+// Workgroup size of k_shade.  Each workgroup pass ends in one atomic on the length of the next queue; at 256 threads
+// the rate of those atomics (all on one address) bounds the kernel, at 512 it runs within a few per cent of the same
+// kernel without compaction, which moves its ~100 bytes per segment at over half of the HBM peak.
+#define RT_SHADE_BS 512
+__global__ void __launch_bounds__(RT_SHADE_BS) k_shade(SceneView S, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
-    __shared__ uint32_t wave_cnt[RT_BS / 64];
+    __shared__ uint32_t wave_cnt[RT_SHADE_BS / 64];
     __shared__ uint32_t block_base;
     const uint32_t count = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * RT_BS; base < count; base += gridDim.x * RT_BS) {
+    for (uint32_t base = blockIdx.x * RT_SHADE_BS; base < count; base += gridDim.x * RT_SHADE_BS) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false;
         Ray r; V3 thr; uint32_t path = 0, pixel = 0;
@@ -222,7 +226,7 @@ __global__ void __launch_bounds__(RT_BS) k_shade(SceneView S, PassParams P, RayQ
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t total = 0;
-            for (int w = 0; w < RT_BS / 64; ++w) { uint32_t c = wave_cnt[w]; wave_cnt[w] = total; total += c; }
+            for (int w = 0; w < RT_SHADE_BS / 64; ++w) { uint32_t c = wave_cnt[w]; wave_cnt[w] = total; total += c; }
             block_base = total ? atomicAdd(next_count, total) : 0u;
         }
         __syncthreads();
@@ -709,6 +713,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         P.sample_base = (uint32_t)s0; P.n_paths = ns * n_owned;
         const uint32_t grid_full = (P.n_paths + RT_BS - 1) / RT_BS;
         const uint32_t grid = std::min(grid_full, max_grid);
+        const uint32_t shade_grid = std::min((P.n_paths + RT_SHADE_BS - 1) / RT_SHADE_BS, max_grid * RT_BS / RT_SHADE_BS);
         const uint32_t trav_grid = std::min((P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, (uint32_t)prop.multiProcessorCount);
         if ((st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
         hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, stream, P, sc->q[0], sc->counts, n_counts);
@@ -729,7 +734,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->hits, b);
             if ((st = L.end(ev)) != RT_OK) return st;
             if ((st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->hits, sc->q[cur ^ 1], sc->counts + b,
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(RT_SHADE_BS), 0, stream, sc->view, P, sc->q[cur], sc->hits, sc->q[cur ^ 1], sc->counts + b,
                                sc->counts + b + 1, sc->values, b);
             if ((st = L.end(ev)) != RT_OK) return st;
             cur ^= 1;
