@@ -17,6 +17,8 @@
 #include <stdint.h>
 
 #include "../../include/rt_abi.h"
+#include <cstring>
+#include <vector>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -111,7 +113,7 @@ RT_HD float medium_variate(const DrawKey& k, uint32_t prim) {
 struct SceneView {
     const rt_prim* prims; const rt_sphere* spheres; const rt_rect* rects; const rt_box* boxes; const rt_xform* xforms;
     const rt_material* materials; const rt_texture* textures; const rt_image* images; const uint8_t* texels;
-    const uint8_t* perm; const rt_bvh_node* bvh;
+    const uint8_t* perm; const struct WalkNode* bvh;  // bvh: n_bvh_nodes slots and one sentinel slot (make_walk_nodes)
     uint32_t n_prims, n_bvh_nodes;
     float background[3];
 };
@@ -398,15 +400,54 @@ struct Ray {
 // reference's left-then-right order.  Node boxes are widened by the host, so the fp32 slab
 // test errs on the side of visiting.
 //
-// Bits of rt_bvh_node.prim on a leaf: the primitive id (RT_NODE_PRIM_MASK) and RT_BVH_EXACT from the host, plus two
-// that the library sets on its own device copy of the array (the arithmetic is the same with or without them; they
-// only say where the numbers are):
+// The walk runs on the library's own copy of the node array (make_walk_nodes below): 32-byte slots with the bounds
+// paired per axis, the caller's leaf bits (primitive id = RT_NODE_PRIM_MASK, RT_BVH_EXACT) and two more that only say
+// where the numbers of a leaf's primitive are (the arithmetic is the same with or without them):
 //   RT_NODE_PLAIN_BOX     exact leaf whose primitive is a box without wrappers or medium: the leaf's box is the geometry;
 //   RT_NODE_PLAIN_SPHERE  leaf of a Sphere without wrappers or medium: the array slot after the leaf holds
 //                         {center.x, center.y, center.z, radius} as four doubles (the leaf's skip link jumps over it).
+// The slot after the last node is a sentinel (skip link to itself) that a finished or idle walk may read.
 #define RT_NODE_PRIM_MASK 0x1FFFFFFFu
 #define RT_NODE_PLAIN_BOX 0x40000000u
 #define RT_NODE_PLAIN_SPHERE 0x20000000u
+
+struct WalkNode { float x0, x1, y0, y1, z0, z1; uint32_t skip, prim; };
+static_assert(sizeof(WalkNode) == 32, "node slot size");
+
+// (host side) The walk's node array for a scene description: payload slots inserted, skip links remapped, leaves annotated,
+// sentinel appended.  nodes.size() - 1 is the SceneView's n_bvh_nodes.
+inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes) {
+    std::vector<uint32_t> new_index(D->n_bvh_nodes + 1);
+    auto plain_sphere = [&](const rt_bvh_node& N) {
+        if (N.prim == RT_BVH_NONE) return false;
+        const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
+        return Pp.geom == RT_GEOM_SPHERE && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM);
+    };
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) { new_index[i] = at; at += plain_sphere(D->bvh[i]) ? 2u : 1u; }
+    new_index[D->n_bvh_nodes] = at;
+    nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at, RT_BVH_NONE});
+    for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) {
+        const rt_bvh_node& N = D->bvh[i];
+        WalkNode W{N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2], new_index[N.skip], N.prim};
+        if (N.prim != RT_BVH_NONE) {
+            const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
+            if (plain_sphere(N)) {
+                W.prim |= RT_NODE_PLAIN_SPHERE;
+                const rt_sphere& sp = D->spheres[Pp.geom_index];
+                const double payload[4] = {sp.center[0], sp.center[1], sp.center[2], sp.radius};
+                static_assert(sizeof(payload) == sizeof(WalkNode), "payload slot size");
+                std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
+            } else if ((N.prim & RT_BVH_EXACT) && Pp.geom == RT_GEOM_BOX && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM)) {
+                const rt_box& B = D->boxes[Pp.geom_index];
+                bool same = true;
+                for (int c = 0; c < 3; ++c) same = same && B.min[c] == N.min[c] && B.max[c] == N.max[c];
+                if (same) W.prim |= RT_NODE_PLAIN_BOX;
+            }
+        }
+        nodes[new_index[i]] = W;
+    }
+}
 
 struct Walk {
     uint32_t i;     // next node to look at
@@ -419,20 +460,43 @@ struct Walk {
 };
 RT_HD void walk_init(Walk& w, float tmax) { w.i = 0; w.leaf_node = 0; w.tmax = tmax; w.t = 0.0f; w.prim = 0; w.side = 0; w.found = false; }
 
+// Slab test of a node with the ray given as (1 / direction, origin / direction): the two bounds of an axis are one
+// pair, so the six (bound * inv - oi) are three two-wide fused multiply-adds on the GPU.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float F2 __attribute__((ext_vector_type(2)));
+RT_HD F2 fma2(float a0, float a1, float b, float c) { const F2 a = {a0, a1}, bb = {b, b}, cc = {c, c}; return __builtin_elementwise_fma(a, bb, cc); }
+#else
+struct F2 { float x, y; };
+RT_HD F2 fma2(float a0, float a1, float b, float c) { F2 r; r.x = fmaf(a0, b, c); r.y = fmaf(a1, b, c); return r; }
+#endif
+RT_HD bool node_hit(const WalkNode& N, V3 inv, V3 oi, float tmin, float tmax) {
+    const F2 x = fma2(N.x0, N.x1, inv.x, -oi.x), y = fma2(N.y0, N.y1, inv.y, -oi.y), z = fma2(N.z0, N.z1, inv.z, -oi.z);
+    const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), tmin));
+    const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), tmax));
+    return tn <= tf;
+}
+
 // One node step.  Returns the leaf's prim field when the ray now stands on a leaf whose primitive has to be
 // tried (w.i already points past it), RT_BVH_NONE otherwise.  Requires w.i < S.n_bvh_nodes.
 RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w) {
-    const rt_bvh_node N = S.bvh[w.i];
+    const WalkNode N = S.bvh[w.i];
     RT_COUNT(nodes);
-    float x0 = fmaf(N.min[0], inv.x, -oi.x), x1 = fmaf(N.max[0], inv.x, -oi.x);
-    float y0 = fmaf(N.min[1], inv.y, -oi.y), y1 = fmaf(N.max[1], inv.y, -oi.y);
-    float z0 = fmaf(N.min[2], inv.z, -oi.z), z1 = fmaf(N.max[2], inv.z, -oi.z);
-    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), w.tmax));
-    if (!(tn <= tf)) { w.i = N.skip; return RT_BVH_NONE; }
+    if (!node_hit(N, inv, oi, tmin, w.tmax)) { w.i = N.skip; return RT_BVH_NONE; }
     w.leaf_node = w.i;
     w.i = (N.prim != RT_BVH_NONE) ? N.skip : w.i + 1;  // a leaf's skip link also jumps over its payload slot, if any
     return N.prim;
+}
+// The same step without control flow, for lanes in lockstep: a walk that already waits on a leaf (leaf != RT_BVH_NONE)
+// or has left the tree (w.i == S.n_bvh_nodes, the sentinel slot) stays as it is.
+RT_HD void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& leaf) {
+    const WalkNode N = S.bvh[w.i];
+    const bool go = leaf == RT_BVH_NONE;
+    const bool hit = node_hit(N, inv, oi, tmin, w.tmax) && go && w.i < S.n_bvh_nodes;
+    const bool on_leaf = hit && N.prim != RT_BVH_NONE;
+    const uint32_t next = (hit && N.prim == RT_BVH_NONE) ? w.i + 1 : N.skip;
+    w.leaf_node = on_leaf ? w.i : w.leaf_node;
+    leaf = on_leaf ? N.prim : leaf;
+    w.i = go ? next : w.i;
 }
 
 // The primitive test of the leaf at node w.leaf_node: Object::scatter's intersect (lib.rs:284-285) behind the
@@ -453,9 +517,10 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, 
     if (!(leaf & RT_BVH_EXACT)) return false;
     // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: (bound - origin) over the direction,
     // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
-    const rt_bvh_node N = S.bvh[w.leaf_node];
+    const WalkNode N = S.bvh[w.leaf_node];
+    const float bmin[3] = {N.x0, N.y0, N.z0}, bmax[3] = {N.x1, N.y1, N.z1};
     float q[6];
-    box_quotients(N.min, N.max, r.o, inv, q);
+    box_quotients(bmin, bmax, r.o, inv, q);
     float lo = tmin, hi = w.tmax;
     lo = fmaxf(r.d.x < 0.0f ? q[1] : q[0], lo); hi = fminf(r.d.x < 0.0f ? q[0] : q[1], hi);
     bool enter = !(hi <= lo);
@@ -472,7 +537,7 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, 
     if (!plain) return false;
     RT_COUNT(leaves); RT_COUNT(prim_tests);
     float t; int side;  // the leaf's box is the box: same arithmetic as box_t<float>, without fetching it
-    if (box_sides_q(N.min, N.max, r.o, r.d, q, tmin, w.tmax, t, side)) walk_accept(w, t, prim, side);
+    if (box_sides_q(bmin, bmax, r.o, r.d, q, tmin, w.tmax, t, side)) walk_accept(w, t, prim, side);
     return true;
 }
 // Everything else: the general Intersection::intersect.  (An exact leaf arrives here only after walk_leaf_fast

@@ -94,9 +94,9 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
     SceneView V = S;
     if (NODES_IN_LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(S.bvh);
-        for (uint32_t k = threadIdx.x; k < 2u * S.n_bvh_nodes; k += blockDim.x) lds[k] = src[k];
+        for (uint32_t k = threadIdx.x; k < 2u * (S.n_bvh_nodes + 1u); k += blockDim.x) lds[k] = src[k];  // with the sentinel slot
         __syncthreads();
-        V.bvh = reinterpret_cast<const rt_bvh_node*>(lds);
+        V.bvh = reinterpret_cast<const WalkNode*>(lds);
     }
     return V;
 }
@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
     Ray r; r.o = v3(0, 0, 0); r.d = v3(1, 1, 1); r.time = 0.0f;
     V3 inv = v3(1, 1, 1), oi = v3(0, 0, 0);
     Walk w; walk_init(w, RT_INF_F);
+    w.i = n_nodes;  // a lane without a ray rests on the sentinel slot
     uint32_t slot = 0, path = 0, pixel = 0, leaf = RT_BVH_NONE;
     if (n_nodes == 0)  // nothing to hit: every ray misses
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) hits[i] = make_uint2(0u, RT_HIT_NONE);
@@ -177,8 +178,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
         const unsigned long long searching = act & ~waiting;
         if (searching != 0ull && (uint32_t)__popcll(waiting) < RT_LEAF_BATCH) {
 #pragma unroll
-            for (int k = 0; k < RT_STEPS_PER_TURN; ++k)
-                if (active && leaf == RT_BVH_NONE && w.i < n_nodes) leaf = walk_step(S, inv, oi, tmin, w);
+            for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, leaf);
         } else {
             if (active && leaf != RT_BVH_NONE) {
                 if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, make_key(P, path, pixel, bounce), leaf, w);
@@ -529,39 +529,11 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     UP(images, D->images, D->n_images);
     UP(texels, D->texels, D->texel_bytes);
     UP(perm, D->perm_tables, 256u * (size_t)D->n_perm_tables);
-    {   // device copy of the node array with the leaf annotations and payload slots of rt_core.h
-        std::vector<uint32_t> new_index(D->n_bvh_nodes + 1);
-        auto plain_sphere = [&](const rt_bvh_node& N) {
-            if (N.prim == RT_BVH_NONE) return false;
-            const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
-            return Pp.geom == RT_GEOM_SPHERE && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM);
-        };
-        uint32_t at = 0;
-        for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) { new_index[i] = at; at += plain_sphere(D->bvh[i]) ? 2u : 1u; }
-        new_index[D->n_bvh_nodes] = at;
-        std::vector<rt_bvh_node> nodes(at);
-        for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) {
-            rt_bvh_node N = D->bvh[i];
-            N.skip = new_index[N.skip];
-            if (N.prim != RT_BVH_NONE) {
-                const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
-                if (plain_sphere(N)) {
-                    N.prim |= RT_NODE_PLAIN_SPHERE;
-                    const rt_sphere& sp = D->spheres[Pp.geom_index];
-                    const double payload[4] = {sp.center[0], sp.center[1], sp.center[2], sp.radius};
-                    static_assert(sizeof(payload) == sizeof(rt_bvh_node), "payload slot size");
-                    std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
-                } else if ((N.prim & RT_BVH_EXACT) && Pp.geom == RT_GEOM_BOX && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM)) {
-                    const rt_box& B = D->boxes[Pp.geom_index];
-                    bool same = true;
-                    for (int c = 0; c < 3; ++c) same = same && B.min[c] == N.min[c] && B.max[c] == N.max[c];
-                    if (same) N.prim |= RT_NODE_PLAIN_BOX;
-                }
-            }
-            nodes[new_index[i]] = N;
-        }
+    {   // the walk's own node array (payload slots, leaf annotations, sentinel)
+        std::vector<WalkNode> nodes;
+        make_walk_nodes(D, nodes);
         UP(bvh, nodes.data(), nodes.size());
-        V.n_bvh_nodes = (uint32_t)nodes.size();
+        V.n_bvh_nodes = (uint32_t)nodes.size() - 1;
     }
 #undef UP
     V.n_prims = D->n_prims;
@@ -689,8 +661,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
     const uint32_t max_grid = (uint32_t)prop.multiProcessorCount * 8u;
     // The node array goes to LDS when it fits beside nothing else (160 KB per CU, one 1024-thread workgroup per CU).
-    const size_t node_bytes = (size_t)sc->view.n_bvh_nodes * sizeof(rt_bvh_node);
-    const bool nodes_in_lds = node_bytes > 0 && node_bytes <= 144u * 1024u && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
+    const size_t node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
+    const bool nodes_in_lds = sc->view.n_bvh_nodes > 0 && node_bytes <= 144u * 1024u && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
     if (nodes_in_lds && !sc->lds_attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));

@@ -20,21 +20,27 @@ static inline void twin_count_prim_tests() { g_tc.prim_tests++; }
 using namespace rt;
 
 namespace {
-SceneView view_of(const rt_scene_desc* D) {
+// The scene as the kernels see it: the caller's arrays plus the walk's own node array.
+struct TwinScene {
     SceneView V{};
-    V.prims = D->prims; V.spheres = D->spheres; V.rects = D->rects; V.boxes = D->boxes; V.xforms = D->xforms;
-    V.materials = D->materials; V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables; V.bvh = D->bvh;
-    V.n_prims = D->n_prims; V.n_bvh_nodes = D->n_bvh_nodes;
-    for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
-    return V;
-}
+    std::vector<WalkNode> nodes;
+    explicit TwinScene(const rt_scene_desc* D) {
+        V.prims = D->prims; V.spheres = D->spheres; V.rects = D->rects; V.boxes = D->boxes; V.xforms = D->xforms;
+        V.materials = D->materials; V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
+        make_walk_nodes(D, nodes);
+        V.bvh = nodes.data();
+        V.n_prims = D->n_prims; V.n_bvh_nodes = (uint32_t)nodes.size() - 1;
+        for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
+    }
+    TwinScene(const TwinScene&) = delete;
+};
 }  // namespace
 
 extern "C" {
 
 void twin_intersect_batch(const rt_scene_desc* D, int64_t scope, const rt_ray* rays, uint64_t n, float tmin, float tmax, uint64_t seed,
                           const float* medium_u, rt_hit* out) {
-    SceneView S = view_of(D);
+    const TwinScene scene(D); const SceneView& S = scene.V;
     for (uint64_t i = 0; i < n; ++i) {
         Ray r; r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
         r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]); r.time = rays[i].time;
@@ -67,7 +73,7 @@ void twin_camera_rays(const rt_camera* cam, uint32_t width, uint32_t height, uin
 // One shading event on a given hit record: returns scattered flag, colour, new ray.
 void twin_material_scatter(const rt_scene_desc* D, const rt_hit* h, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, int32_t* scattered,
                            float* color, float* ray_o, float* ray_d) {
-    SceneView S = view_of(D);
+    const TwinScene scene(D); const SceneView& S = scene.V;
     Hit hh; hh.t = h->t; hh.u = h->u; hh.v = h->v; hh.prim = h->prim;
     hh.point = v3(h->point[0], h->point[1], h->point[2]); hh.normal = v3(h->normal[0], h->normal[1], h->normal[2]);
     hh.in_vec = v3(h->in_vec[0], h->in_vec[1], h->in_vec[2]);
@@ -81,7 +87,7 @@ void twin_material_scatter(const rt_scene_desc* D, const rt_hit* h, uint64_t see
 // Per-ray traversal work (nodes visited, leaves reached, primitive tests run) for analysis.
 // trace (optional, n x trace_cap): the node-visit count at which each leaf was reached.
 void twin_traverse_stats(const rt_scene_desc* D, const rt_ray* rays, uint64_t n, uint64_t seed, uint32_t* out /* n x 3 */, uint32_t* trace, uint32_t trace_cap) {
-    SceneView S = view_of(D);
+    const TwinScene scene(D); const SceneView& S = scene.V;
     for (uint64_t i = 0; i < n; ++i) {
         Ray r; r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
         r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]); r.time = rays[i].time;
@@ -97,7 +103,7 @@ void twin_traverse_stats(const rt_scene_desc* D, const rt_ray* rays, uint64_t n,
 // Returns the number of segments written.
 uint32_t twin_trace_sample(const rt_scene_desc* D, const rt_camera* cam, uint32_t width, uint32_t height, uint32_t i, uint32_t j, uint32_t sample, uint32_t depth,
                            uint64_t seed, float* out, uint32_t cap) {
-    SceneView S = view_of(D);
+    const TwinScene scene(D); const SceneView& S = scene.V;
     Ray r = camera_ray(*cam, i, j, width, height, sample, (uint32_t)seed, (uint32_t)(seed >> 32));
     V3 thr = v3(1, 1, 1), value = v3(0, 0, 0);
     DrawKey key; key.k0 = (uint32_t)seed; key.k1 = (uint32_t)(seed >> 32); key.pixel = j * width + i; key.sample = sample; key.medium_u = -1.0f;
@@ -127,7 +133,7 @@ uint8_t twin_quantise(double x) { return quantise(x); }
 // i.e. what the kernels compute, on host threads.  mean_out: 3*w*h doubles, top row first.
 void twin_render(const rt_scene_desc* D, const rt_camera* cam, uint32_t width, uint32_t height, uint64_t spp, uint64_t depth, uint64_t seed, int threads,
                  double* mean_out) {
-    SceneView S = view_of(D);
+    const TwinScene scene(D); const SceneView& S = scene.V;
     std::atomic<uint32_t> next_row(0);
     auto worker = [&]() {
             for (;;) {
