@@ -404,8 +404,11 @@ struct Ray {
 // paired per axis, the caller's leaf bits (primitive id = RT_NODE_PRIM_MASK, RT_BVH_EXACT) and two more that only say
 // where the numbers of a leaf's primitive are (the arithmetic is the same with or without them):
 //   RT_NODE_PLAIN_BOX     exact leaf whose primitive is a box without wrappers or medium: the leaf's box is the geometry;
-//   RT_NODE_PLAIN_SPHERE  leaf of a Sphere without wrappers or medium: the array slot after the leaf holds
+//   RT_NODE_PLAIN_SPHERE  leaf of a Sphere that is not a medium's boundary: the array slot after the leaf holds
 //                         {center.x, center.y, center.z, radius} as four doubles (the leaf's skip link jumps over it).
+//                         Behind Translated / Rotated wrappers the centre is the wrapped sphere's centre carried out
+//                         through the wrappers: the near root along the ray in the outer frame is the near root along
+//                         the transformed ray in the sphere's frame (rotations keep lengths), to a few f64 ulps.
 // The slot after the last node is a sentinel (skip link to itself) that a finished or idle walk may read.
 #define RT_NODE_PRIM_MASK 0x1FFFFFFFu
 #define RT_NODE_PLAIN_BOX 0x40000000u
@@ -414,28 +417,83 @@ struct Ray {
 struct WalkNode { float x0, x1, y0, y1, z0, z1; uint32_t skip, prim; };
 static_assert(sizeof(WalkNode) == 32, "node slot size");
 
-// (host side) The walk's node array for a scene description: payload slots inserted, skip links remapped, leaves annotated,
-// sentinel appended.  nodes.size() - 1 is the SceneView's n_bvh_nodes.
+// (host side) Inner nodes that cost more than they save are taken out of the pre-order array, their children moving up to
+// the parent (the array allows any number of children: a node's children are the nodes between it and its skip link).
+// The walk tests every child of a node it enters, so an inner node N with c children under a parent is worth its own
+// test only if the chance that a ray in the parent's box also meets N's box, about area(N) / area(parent), is below
+// 1 - 1/c; median splits along one axis leave children with some 2/3 of their parent's area, so about every second
+// level goes.  Leaves, their order and their boxes stay as they are; inner boxes only cull, so hits do not change.
+inline void prune_inner_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_node>& out) {
+    out.clear();
+    if (n == 0) return;
+    auto area = [](const rt_bvh_node& N) {
+        const double dx = (double)N.max[0] - N.min[0], dy = (double)N.max[1] - N.min[1], dz = (double)N.max[2] - N.min[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    };
+    // kids[i]: the children of inner node i after pruning below it (indices into `in`), found bottom-up (children come
+    // after their parent in pre-order, so a descending loop sees them first)
+    std::vector<std::vector<uint32_t>> kids(n);
+    for (uint32_t i = n; i-- > 0;) {
+        if (in[i].prim != RT_BVH_NONE) continue;
+        const double a = area(in[i]);
+        for (uint32_t c = i + 1; c < in[i].skip && c < n; c = in[c].skip) {
+            const size_t nk = kids[c].size();
+            const bool inner = in[c].prim == RT_BVH_NONE;
+            const double ratio = a > 0.0 ? area(in[c]) / a : 1.0;
+            if (inner && (nk == 0 || !(ratio <= 1.0 - 1.0 / (double)nk))) kids[i].insert(kids[i].end(), kids[c].begin(), kids[c].end());
+            else kids[i].push_back(c);
+            if (in[c].skip <= c) break;  // malformed link: stop rather than loop (the caller has validated the array)
+        }
+    }
+    // emit in pre-order with an explicit stack; skip = index after the subtree
+    struct Frame { uint32_t node; size_t next_kid; uint32_t at; };
+    std::vector<Frame> stack;
+    out.push_back(in[0]);
+    stack.push_back({0u, 0, 0u});
+    while (!stack.empty()) {
+        Frame& f = stack.back();
+        if (in[f.node].prim != RT_BVH_NONE || f.next_kid == kids[f.node].size()) {
+            out[f.at].skip = (uint32_t)out.size();
+            stack.pop_back();
+            continue;
+        }
+        const uint32_t c = kids[f.node][f.next_kid++];
+        out.push_back(in[c]);
+        stack.push_back({c, 0, (uint32_t)out.size() - 1});
+    }
+}
+
+// (host side) The walk's node array for a scene description: inner nodes pruned, payload slots inserted, skip links
+// remapped, leaves annotated, sentinel appended.  nodes.size() - 1 is the SceneView's n_bvh_nodes.
 inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes) {
-    std::vector<uint32_t> new_index(D->n_bvh_nodes + 1);
+    std::vector<rt_bvh_node> tree;
+    prune_inner_nodes(D->bvh, D->n_bvh_nodes, tree);
+    const uint32_t n_in = (uint32_t)tree.size();
+    std::vector<uint32_t> new_index(n_in + 1);
     auto plain_sphere = [&](const rt_bvh_node& N) {
         if (N.prim == RT_BVH_NONE) return false;
         const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
-        return Pp.geom == RT_GEOM_SPHERE && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM);
+        return Pp.geom == RT_GEOM_SPHERE && !(Pp.flags & RT_PRIM_MEDIUM);
     };
     uint32_t at = 0;
-    for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) { new_index[i] = at; at += plain_sphere(D->bvh[i]) ? 2u : 1u; }
-    new_index[D->n_bvh_nodes] = at;
+    for (uint32_t i = 0; i < n_in; ++i) { new_index[i] = at; at += plain_sphere(tree[i]) ? 2u : 1u; }
+    new_index[n_in] = at;
     nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at, RT_BVH_NONE});
-    for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) {
-        const rt_bvh_node& N = D->bvh[i];
+    for (uint32_t i = 0; i < n_in; ++i) {
+        const rt_bvh_node& N = tree[i];
         WalkNode W{N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2], new_index[N.skip], N.prim};
         if (N.prim != RT_BVH_NONE) {
             const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
             if (plain_sphere(N)) {
                 W.prim |= RT_NODE_PLAIN_SPHERE;
                 const rt_sphere& sp = D->spheres[Pp.geom_index];
-                const double payload[4] = {sp.center[0], sp.center[1], sp.center[2], sp.radius};
+                D3 c = d3(sp.center);
+                for (uint32_t k = Pp.xf_count; k > 0; --k) {  // innermost wrapper first, as prim_surface carries a point out
+                    const rt_xform& X = D->xforms[Pp.xf_first + k - 1];
+                    if (X.kind == RT_XF_TRANSLATE) c = c + d3(X.a, X.b, X.c);
+                    else c = rotate_cs(c, X.kind, X.a, X.b);
+                }
+                const double payload[4] = {c.x, c.y, c.z, sp.radius};
                 static_assert(sizeof(payload) == sizeof(WalkNode), "payload slot size");
                 std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
             } else if ((N.prim & RT_BVH_EXACT) && Pp.geom == RT_GEOM_BOX && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM)) {

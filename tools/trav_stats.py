@@ -1,0 +1,25 @@
+"""Traversal work per path segment on the CPU build of the kernel code: node tests, leaves reached and primitive tests
+for the rays of a few hundred camera paths (final_scene unless another example is named)."""
+import ctypes as C
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import raytracing_amd as rt
+from raytracing_amd import _abi
+from oracle_lib import OracleScene, TWIN_PATH, rays_to_c
+from scenes_util import path_rays
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'final_scene'
+earth = rt.earthmap() if name == 'final_scene' else None
+sc, co = rt.Scene.example(name, 1, earth)
+osc, oco = OracleScene.example(name, 1, earth)
+lib = C.CDLL(TWIN_PATH)
+lib.twin_traverse_stats.argtypes = [C.POINTER(_abi.rt_scene_desc), C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32]
+desc = sc._host.rth_scene_desc(sc._h)
+tot = np.zeros(3); n = 0
+for o, d, t in path_rays(osc, oco, 64, 64, 5, 3000, 12, np.random.default_rng(3)):
+    rays = rays_to_c(o, d, t)
+    out = np.zeros((len(rays), 3), dtype=np.uint32)
+    lib.twin_traverse_stats(desc, rays.ctypes.data, len(rays), 1, out.ctypes.data, None, 0)
+    tot += out.sum(axis=0); n += len(rays)
+print(name, 'segments', n, 'nodes/seg %.2f leaves/seg %.2f prim tests/seg %.2f' % tuple(tot / n))
