@@ -169,6 +169,30 @@ RT_HD D3 sphere_center(const rt_sphere& sp, bool moving, float time) {
     }
     return c;
 }
+// Square root and reciprocal in f64 for the sphere's root.  On the GPU: the hardware estimate refined to within an ulp
+// or two (a quarter of the instructions of the correctly rounded library routines; the root is rounded to fp32
+// afterwards).  On the host: the plain operations.
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_HD double sqrt_near(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+RT_HD double rcp_near(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+#else
+RT_HD double sqrt_near(double x) { return sqrt(x); }
+RT_HD double rcp_near(double x) { return 1.0 / x; }
+#endif
 // Near root (-half_b - sqrt(disc)) / a of shape.rs:262-270; false when the discriminant is negative.
 RT_HD bool sphere_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time, double& t_out) {
     D3 c = sphere_center(sp, moving, time);
@@ -178,7 +202,7 @@ RT_HD bool sphere_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time
     double cc = dot(oc, oc) - sp.radius * sp.radius;
     double disc = half_b * half_b - a * cc;
     if (disc < 0.0) return false;
-    t_out = (-half_b - sqrt(disc)) / a;
+    t_out = (-half_b - sqrt_near(disc)) * rcp_near(a);
     return true;
 }
 
@@ -544,16 +568,21 @@ RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w)
     w.i = (N.prim != RT_BVH_NONE) ? N.skip : w.i + 1;  // a leaf's skip link also jumps over its payload slot, if any
     return N.prim;
 }
-// The same step without control flow, for lanes in lockstep: a walk that already waits on a leaf (leaf != RT_BVH_NONE)
-// or has left the tree (w.i == S.n_bvh_nodes, the sentinel slot) stays as it is.
-RT_HD void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& leaf) {
+// The same step without control flow, for lanes in lockstep, with up to two leaves left pending: a leaf the walk meets
+// is noted (its node index, oldest in p0) and the walk goes on; the primitive tests are made later, oldest first.
+// That changes no result: the tests still run in leaf order against the bound as it is then, a walk that goes on with a
+// bound not yet lowered only visits nodes it might have skipped, and a leaf reached that way fails its test (its
+// primitive lies inside its box, beyond the bound; exact leaves repeat their box test when they are tried).
+// A walk with two leaves pending, or one that has left the tree (w.i == S.n_bvh_nodes, the sentinel slot), stays as it is.
+RT_HD void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& p0, uint32_t& p1) {
     const WalkNode N = S.bvh[w.i];
-    const bool go = leaf == RT_BVH_NONE;
+    const bool go = p1 == RT_BVH_NONE;
     const bool hit = node_hit(N, inv, oi, tmin, w.tmax) && go && w.i < S.n_bvh_nodes;
     const bool on_leaf = hit && N.prim != RT_BVH_NONE;
     const uint32_t next = (hit && N.prim == RT_BVH_NONE) ? w.i + 1 : N.skip;
-    w.leaf_node = on_leaf ? w.i : w.leaf_node;
-    leaf = on_leaf ? N.prim : leaf;
+    const bool first = p0 == RT_BVH_NONE;
+    p1 = (on_leaf && !first) ? w.i : p1;
+    p0 = (on_leaf && first) ? w.i : p0;
     w.i = go ? next : w.i;
 }
 

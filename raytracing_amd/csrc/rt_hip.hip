@@ -101,24 +101,27 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
     return V;
 }
 
-// Closest hit for every ray of the queue: persistent waves with a flat per-lane state machine.
+// Closest hit for every ray of the queue: persistent waves, every lane walking its own ray.
 //
-// A lane is either searching (stepping over BVH nodes), waiting on a leaf (its primitive test is due) or idle.
-// Each turn of the loop the wave either makes one node step for its searching lanes, or, once enough lanes
-// wait on a leaf (or nobody is searching), runs the primitive tests of all waiting lanes together; lanes whose
-// ray is finished take the next ray of the workgroup's share of the queue (one LDS atomic per wave and turn).
-// This keeps the long primitive tests from running for a handful of lanes at a time and keeps lanes busy
-// although rays need very different numbers of steps (20 to 200 on final_scene).
-// The per-ray arithmetic is walk_step / walk_leaf of rt_core.h, exactly what closest_hit() runs.
+// A lane has a ray or is idle; a lane with a ray steps over BVH nodes and notes the leaves it meets (up to two, see
+// walk_step_flat), whose primitive tests are made later.  Each turn of the loop the wave either makes a run of node
+// steps (branch-free, all lanes in lockstep) or, once enough lanes have a leaf pending or can no longer step, runs
+// the oldest pending primitive test of every lane that has one; lanes whose ray is finished take the next ray of the
+// workgroup's share of the queue (one LDS atomic per wave and turn).  The long primitive tests thus run for most of
+// the wave at a time, and lanes stay busy although rays need very different numbers of steps (20 to 200 on
+// final_scene).  The per-ray arithmetic is that of closest_hit() in rt_core.h.
 #ifndef RT_LEAF_BATCH
-#define RT_LEAF_BATCH 40      // run the primitive tests once this many of the 64 lanes wait on a leaf
+#define RT_LEAF_BATCH 48      // run the primitive tests once this many of the 64 lanes have a leaf pending
 #endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 12      // fetch new rays once this many lanes are idle (a fetch waits on global memory)
 #endif
 #define RT_TRAV_GROUP 256u    // rays dealt to a workgroup at a time
+#ifndef RT_STUCK_MAX
+#define RT_STUCK_MAX 16       // ... or once this many lanes cannot step (two leaves pending, or out of the tree with one)
+#endif
 #ifndef RT_STEPS_PER_TURN
-#define RT_STEPS_PER_TURN 4   // node steps between two looks at the wave's state
+#define RT_STEPS_PER_TURN 8   // node steps between two looks at the wave's state
 #endif
 template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
     V3 inv = v3(1, 1, 1), oi = v3(0, 0, 0);
     Walk w; walk_init(w, RT_INF_F);
     w.i = n_nodes;  // a lane without a ray rests on the sentinel slot
-    uint32_t slot = 0, path = 0, pixel = 0, leaf = RT_BVH_NONE;
+    uint32_t slot = 0, path = 0, pixel = 0, p0 = RT_BVH_NONE, p1 = RT_BVH_NONE;  // p0, p1: pending leaves (node indices), oldest first
     if (n_nodes == 0)  // nothing to hit: every ray misses
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) hits[i] = make_uint2(0u, RT_HIT_NONE);
     for (;;) {
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
                 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
                 walk_init(w, RT_INF_F);
-                slot = mine; leaf = RT_BVH_NONE;
+                slot = mine; p0 = RT_BVH_NONE; p1 = RT_BVH_NONE;
                 active = true;
             }
         }
@@ -174,18 +177,21 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
             if (exhausted) break;
             continue;
         }
-        const unsigned long long waiting = __ballot(active && leaf != RT_BVH_NONE);
-        const unsigned long long searching = act & ~waiting;
-        if (searching != 0ull && (uint32_t)__popcll(waiting) < RT_LEAF_BATCH) {
+        const unsigned long long pending = __ballot(active && p0 != RT_BVH_NONE);
+        const unsigned long long runnable = __ballot(active && p1 == RT_BVH_NONE && w.i < n_nodes);
+        const unsigned long long stuck = act & ~runnable & pending;  // two leaves pending, or out of the tree with one
+        if (runnable != 0ull && (uint32_t)__popcll(pending) < RT_LEAF_BATCH && (uint32_t)__popcll(stuck) < RT_STUCK_MAX) {
 #pragma unroll
-            for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, leaf);
+            for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, p0, p1);
         } else {
-            if (active && leaf != RT_BVH_NONE) {
+            if (active && p0 != RT_BVH_NONE) {
+                w.leaf_node = p0;
+                const uint32_t leaf = S.bvh[p0].prim;
                 if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, make_key(P, path, pixel, bounce), leaf, w);
-                leaf = RT_BVH_NONE;
+                p0 = p1; p1 = RT_BVH_NONE;
             }
         }
-        if (active && leaf == RT_BVH_NONE && w.i >= n_nodes) {
+        if (active && p0 == RT_BVH_NONE && w.i >= n_nodes) {
             hits[slot] = make_uint2(__float_as_uint(w.t), w.found ? (w.prim | ((uint32_t)w.side << 29)) : RT_HIT_NONE);
             active = false;
         }

@@ -99,6 +99,37 @@ void twin_traverse_stats(const rt_scene_desc* D, const rt_ray* rays, uint64_t n,
     }
 }
 
+// What-if analysis: the same walk with up to `defer` leaves left pending (their primitive tests run, in order, only when
+// the list is full or the tree is exhausted) while the walk goes on with the old upper bound.  out: node tests per ray.
+void twin_traverse_deferred(const rt_scene_desc* D, const rt_ray* rays, uint64_t n, uint32_t defer, uint32_t* out) {
+    const TwinScene scene(D); const SceneView& S = scene.V;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r; r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]); r.time = rays[i].time;
+        DrawKey key; key.k0 = 1; key.k1 = 0; key.pixel = (uint32_t)i; key.sample = 0; key.bounce = 0; key.medium_u = -1.0f;
+        const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+        Walk w; walk_init(w, RT_INF_F);
+        uint32_t pend_leaf[16], pend_node[16], n_pend = 0, nodes = 0;
+        auto flush = [&]() {
+            for (uint32_t k = 0; k < n_pend; ++k) {
+                w.leaf_node = pend_node[k];
+                if (!walk_leaf_fast(S, r, inv, 0.001f, pend_leaf[k], w)) walk_leaf_generic(S, r, 0.001f, key, pend_leaf[k], w);
+            }
+            n_pend = 0;
+        };
+        while (w.i < S.n_bvh_nodes) {
+            ++nodes;
+            const uint32_t leaf = walk_step(S, inv, oi, 0.001f, w);
+            if (leaf == RT_BVH_NONE) continue;
+            pend_leaf[n_pend] = leaf; pend_node[n_pend] = w.leaf_node; ++n_pend;
+            if (n_pend >= defer) flush();
+        }
+        flush();
+        out[i] = nodes;
+    }
+}
+
 // One camera path, bounce by bounce: out holds 12 floats per segment (origin, direction, t, prim or -1, throughput, value.x).
 // Returns the number of segments written.
 uint32_t twin_trace_sample(const rt_scene_desc* D, const rt_camera* cam, uint32_t width, uint32_t height, uint32_t i, uint32_t j, uint32_t sample, uint32_t depth,
