@@ -51,16 +51,29 @@ def algorithmic_flops(cnt):
     return trav, shade, raygen
 
 
-def cpu_baseline_and_work(earth):
-    """Times the oracle on final_scene at 320x320, 96 spp (9.8 M samples of the full view, 10-30 s on 16 cores),
-    then counts work on a smaller run."""
+def hbm_traffic_per_launch(kernel, segments_per_launch):
+    """HBM bytes of one launch of `kernel`: the bytes per path segment measured with the rocprofv3 PMC counters (kept with
+    their derivation in profiles/) times the segments of this run's average launch.  None without that file."""
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if not files:
+        return None
+    with open(os.path.join(ROOT, "profiles", files[-1])) as fh:
+        per_segment = json.load(fh)["kernels"][kernel]["bytes_per_segment"]
+    return round(per_segment * segments_per_launch)
+
+
+def cpu_baseline_and_work(earth, timed):
+    """Counts the reference algorithm's work per sample with the oracle (96x96, 8 spp) and, if `timed`, times the oracle on
+    final_scene at 320x320, 96 spp (9.8 M samples of the full view, 10-30 s on 16 cores)."""
     from oracle_lib import OracleScene
     threads = min(16, os.cpu_count() or 1)
     osc, oco = OracleScene.example("final_scene", 1, earth)
+    _, _, _, cnt = osc.render(oco, 96, 96, 8, DEPTH, seed=1, threads=threads, counters=True)
+    if not timed:
+        return None, cnt
     w = h = 320
     spp = 96
     _, _, secs, _ = osc.render(oco, w, h, spp, DEPTH, seed=1, threads=threads, shade_every=True)
-    _, _, _, cnt = osc.render(oco, 96, 96, 8, DEPTH, seed=1, threads=threads, counters=True)
     base = {"value": round(w * h * spp / secs / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
             "sample": f"final_scene {w}x{h}, {spp} spp, depth {DEPTH}: {w * h * spp} samples in {secs:.1f} s; f64 C++ restatement of the reference "
                       f"(reference traversal order, every accepted candidate shaded), {threads} std::threads"}
@@ -123,14 +136,14 @@ def main():
         prof = scene.profile()
         roofline, cpu = None, None
         if not args.no_cpu_baseline:
-            cpu, cnt = cpu_baseline_and_work(earth)
+            cpu, cnt = cpu_baseline_and_work(earth, timed=world == 1)
             trav, shade, raygen = algorithmic_flops(cnt)
             trav_per_seg = trav / cnt["segments"]
             seg_per_launch = prof["traverse_segments"] / max(prof["traverse_launches"], 1)
             ms_per_launch = prof["traverse_ms"] / max(prof["traverse_launches"], 1)
             achieved = trav_per_seg * seg_per_launch / (ms_per_launch * 1e-3) / 1e12
             roofline = {"bound": "valu", "kernel": "k_traverse", "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                        "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": hbm_traffic_per_launch("k_traverse", seg_per_launch),
                         "flops_per_segment": round(trav_per_seg, 1), "segments_per_launch": round(seg_per_launch), "ms_per_launch": round(ms_per_launch, 4),
                         "flops_per_sample_all_kernels": round((trav + shade + raygen) / cnt["samples"], 1),
                         "segments_per_sample": round(cnt["segments"] / cnt["samples"], 2),
