@@ -218,6 +218,10 @@ struct ImageOptions {  // src/lib.rs:108-117
 struct RenderOptions {
     uint64_t seed = 1;
     int device = -1;
+    // More than one entry: the frame's 16x16 tiles are dealt round robin to these devices (one host thread and one
+    // device copy of the scene each), the per-device frames of f64 means are added on the host (adding zeros is
+    // exact) and quantised there; the bytes are those of a single-device render.
+    std::vector<int> devices;
 };
 
 // src/lib.rs:18 -- 3 bytes per pixel, row-major, top row first.  Runs on the GPU
@@ -239,8 +243,13 @@ Example final_scene(Rng& rng, const textures::Texture& earthmap);
 Example by_name(const std::string& name, Rng& rng, const textures::Texture* earthmap);
 }  // namespace examples
 
-// Writes an 8-bit RGB image as binary PPM (stands in for ImageBuffer::save of the examples).
+// lib.rs:68-72: x.max(0).min(1).sqrt() * 255.999 as u8 (saturating, NaN -> 0).
+uint8_t quantise(double mean);
+
+// Writes an 8-bit RGB image as binary PPM / as PNG (stored deflate blocks, no compression); they stand in for
+// ImageBuffer::from_raw(..).save("test.png") of the examples (e.g. cornell.rs:109-116).
 void write_ppm(const std::string& path, uint32_t width, uint32_t height, const std::vector<uint8_t>& rgb);
+void write_png(const std::string& path, uint32_t width, uint32_t height, const std::vector<uint8_t>& rgb);
 
 }  // namespace raytracing
 #endif

@@ -159,6 +159,9 @@ HOST_SYMBOLS.update({
     "rth_example_scene": (_P, [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(camera_options)]),
     "rth_camera_new": (C.c_int, [C.POINTER(camera_options), C.POINTER(rt_camera)]),
     "rth_pixels": (C.c_int, [_P, C.POINTER(camera_options), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
+    "rth_pixels_devices": (C.c_int, [_P, C.POINTER(camera_options), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_int),
+                                     C.c_void_p]),
+    "rth_write_image": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]),
 })
 
 

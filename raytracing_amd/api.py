@@ -393,12 +393,19 @@ class Scene:
         return out
 
 
-def pixels(camera: Camera, scene: Scene, image_options: ImageOptions, seed: int = 1) -> bytes:
-    """`pixels(&camera, &scene, image_options) -> Vec<u8>` (src/lib.rs:18) through the host library's C++ entry."""
+def pixels(camera: Camera, scene: Scene, image_options: ImageOptions, seed: int = 1, devices=None) -> bytes:
+    """`pixels(&camera, &scene, image_options) -> Vec<u8>` (src/lib.rs:18) through the host library's C++ entry.
+    `devices`: device indices to split the frame over (one host thread each); None = the current device."""
     host = _abi.host_lib()
     out = np.zeros(3 * image_options.width * image_options.height, dtype=np.uint8)
     co = camera.options.to_c()
-    if host.rth_pixels(scene._h, C.byref(co), image_options.width, image_options.height, image_options.samples_per_pixel, image_options.max_reflections,
-                       seed, -1, out.ctypes.data_as(C.c_void_p)) != 0:
+    io = image_options
+    if devices is None:
+        rc = host.rth_pixels(scene._h, C.byref(co), io.width, io.height, io.samples_per_pixel, io.max_reflections, seed, -1, out.ctypes.data_as(C.c_void_p))
+    else:
+        dev = (C.c_int * len(devices))(*devices)
+        rc = host.rth_pixels_devices(scene._h, C.byref(co), io.width, io.height, io.samples_per_pixel, io.max_reflections, seed, len(devices), dev,
+                                     out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
         raise RuntimeError(host.rth_last_error().decode())
     return out.tobytes()

@@ -118,4 +118,26 @@ int rth_pixels(void* sc, const rth_camera_options* o, uint32_t width, uint32_t h
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// pixels() with the frame split over several device contexts (RenderOptions::devices)
+int rth_pixels_devices(void* sc, const rth_camera_options* o, uint32_t width, uint32_t height, uint64_t spp, uint64_t max_reflections, uint64_t seed,
+                       uint32_t n_devices, const int* devices, uint8_t* rgb_out) {
+    try {
+        camera::Camera cam(cam_opts(o));
+        RenderOptions ro; ro.seed = seed; ro.devices.assign(devices, devices + n_devices);
+        std::vector<uint8_t> px = pixels(cam, *(Scene*)sc, ImageOptions{height, width, (size_t)spp, (size_t)max_reflections}, ro);
+        std::memcpy(rgb_out, px.data(), px.size());
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// write_ppm / write_png of the host API (path ending in .png selects PNG)
+int rth_write_image(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb) {
+    try {
+        const std::string p(path);
+        std::vector<uint8_t> px(rgb, rgb + (size_t)3 * width * height);
+        if (p.size() >= 4 && p.compare(p.size() - 4, 4, ".png") == 0) write_png(p, width, height, px); else write_ppm(p, width, height, px);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 }  // extern "C"

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <thread>
 #include <limits>
 #include <stdexcept>
 
@@ -514,14 +515,45 @@ rt_scene* Scene::device_scene(int device) const {
     return sc;
 }
 
+uint8_t quantise(double x) {
+    const double y = std::sqrt(std::fmin(std::fmax(x, 0.0), 1.0)) * 255.999;
+    if (!(y > 0.0)) return 0;
+    if (y >= 255.0) return 255;
+    return (uint8_t)y;
+}
+
 std::vector<uint8_t> pixels(const camera::Camera& camera, const Scene& scene, ImageOptions io, const RenderOptions& ro) {
-    rt_scene* sc = scene.device_scene(ro.device);
     rt_image_options o{io.height, io.width, (uint64_t)io.samples_per_pixel, (uint64_t)io.max_reflections};
-    rt_render_options r{};
-    r.seed = ro.seed; r.rank = 0; r.world_size = 1;
     std::vector<uint8_t> out((size_t)3 * io.width * io.height);
-    rt_status st = rt_render(sc, &camera.abi(), &o, &r, out.data(), nullptr);
-    if (st != RT_OK) throw std::runtime_error(std::string("rt_render failed: ") + rt_last_error());
+    if (ro.devices.size() <= 1) {
+        rt_scene* sc = scene.device_scene(ro.devices.empty() ? ro.device : ro.devices[0]);
+        rt_render_options r{};
+        r.seed = ro.seed; r.rank = 0; r.world_size = 1;
+        rt_status st = rt_render(sc, &camera.abi(), &o, &r, out.data(), nullptr);
+        if (st != RT_OK) throw std::runtime_error(std::string("rt_render failed: ") + rt_last_error());
+        return out;
+    }
+    // one thread, one device copy of the scene and one frame of means per device
+    const size_t n_dev = ro.devices.size(), n = out.size();
+    std::vector<std::vector<double>> means(n_dev, std::vector<double>(n));
+    std::vector<std::string> errors(n_dev);
+    std::vector<std::thread> pool;
+    for (size_t k = 0; k < n_dev; ++k)
+        pool.emplace_back([&, k]() {
+            rt_scene* sc = nullptr;
+            if (rt_scene_create(&scene.desc(), ro.devices[k], &sc) != RT_OK) { errors[k] = std::string("rt_scene_create failed: ") + rt_last_error(); return; }
+            rt_render_options r{};
+            r.seed = ro.seed; r.rank = (uint32_t)k; r.world_size = (uint32_t)n_dev;
+            if (rt_render(sc, &camera.abi(), &o, &r, nullptr, means[k].data()) != RT_OK) errors[k] = std::string("rt_render failed: ") + rt_last_error();
+            rt_scene_destroy(sc);
+        });
+    for (auto& t : pool) t.join();
+    for (auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
+    for (size_t i = 0; i < n; ++i) {
+        double sum = 0.0;
+        for (size_t k = 0; k < n_dev; ++k) sum += means[k][i];
+        out[i] = quantise(sum);
+    }
     return out;
 }
 
@@ -530,6 +562,53 @@ void write_ppm(const std::string& path, uint32_t width, uint32_t height, const s
     if (!f) throw std::runtime_error("write_ppm: cannot open " + path);
     f << "P6\n" << width << " " << height << "\n255\n";
     f.write((const char*)rgb.data(), (std::streamsize)rgb.size());
+}
+
+// PNG: signature, IHDR (8-bit RGB), one IDAT holding a zlib stream of stored blocks (filter byte 0 per row), IEND.
+void write_png(const std::string& path, uint32_t width, uint32_t height, const std::vector<uint8_t>& rgb) {
+    if (rgb.size() != (size_t)3 * width * height) throw std::runtime_error("write_png: buffer size does not match the dimensions");
+    static uint32_t crc_table[256];
+    static bool have_table = false;
+    if (!have_table) {
+        for (uint32_t n = 0; n < 256; ++n) { uint32_t c = n; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; crc_table[n] = c; }
+        have_table = true;
+    }
+    auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); };
+    auto chunk = [&](std::ofstream& f, const char* type, const std::vector<uint8_t>& data) {
+        std::vector<uint8_t> head; be32(head, (uint32_t)data.size());
+        f.write((const char*)head.data(), 4);
+        uint32_t c = 0xFFFFFFFFu;
+        for (int k = 0; k < 4; ++k) c = crc_table[(c ^ (uint8_t)type[k]) & 0xFFu] ^ (c >> 8);
+        for (uint8_t b : data) c = crc_table[(c ^ b) & 0xFFu] ^ (c >> 8);
+        f.write(type, 4);
+        f.write((const char*)data.data(), (std::streamsize)data.size());
+        std::vector<uint8_t> tail; be32(tail, c ^ 0xFFFFFFFFu);
+        f.write((const char*)tail.data(), 4);
+    };
+    std::vector<uint8_t> raw;  // scanlines, each behind its filter byte
+    raw.reserve(((size_t)3 * width + 1) * height);
+    for (uint32_t y = 0; y < height; ++y) { raw.push_back(0); raw.insert(raw.end(), rgb.begin() + (size_t)3 * width * y, rgb.begin() + (size_t)3 * width * (y + 1)); }
+    std::vector<uint8_t> z{0x78, 0x01};
+    uint32_t a = 1, b = 0;  // Adler-32 of the uncompressed data
+    for (size_t at = 0; at < raw.size() || at == 0;) {
+        const size_t len = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + len >= raw.size() ? 1 : 0);
+        z.push_back(len & 0xFF); z.push_back(len >> 8); z.push_back(~len & 0xFF); z.push_back((~len >> 8) & 0xFF);
+        for (size_t k = 0; k < len; ++k) { a = (a + raw[at + k]) % 65521u; b = (b + a) % 65521u; }
+        z.insert(z.end(), raw.begin() + at, raw.begin() + at + len);
+        at += len;
+        if (len == 0) break;
+    }
+    be32(z, (b << 16) | a);
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("write_png: cannot open " + path);
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    f.write((const char*)sig, 8);
+    std::vector<uint8_t> ihdr; be32(ihdr, width); be32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(f, "IHDR", ihdr);
+    chunk(f, "IDAT", z);
+    chunk(f, "IEND", {});
 }
 
 // ----------------------------------------------------------------- examples

@@ -188,3 +188,14 @@ def test_quantise_device_matches_reference_rule():
     sc.quantise_device(vals.data_ptr(), 8, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert out.cpu().tolist() == [127, 255, 255, 0, 0, 0, 0, 255]
+
+
+def test_pixels_split_over_device_contexts(earth):
+    """RenderOptions::devices of the C++ host API (what `rt_example --gpus N` uses): the frame split over three device
+    contexts (all on GPU 0 here), means added and quantised on the host -- the bytes of the single-device render."""
+    sc, co = _example("final_scene", earth)
+    cam = rt.Camera(co)
+    io = rt.ImageOptions(50, 70, 6, 50)
+    assert rt.pixels(cam, sc, io, seed=5, devices=[0, 0, 0]) == rt.pixels(cam, sc, io, seed=5)
+    with pytest.raises(RuntimeError):
+        rt.pixels(cam, sc, io, seed=5, devices=[0, 999])

@@ -240,3 +240,58 @@ def test_image_parity_with_common_random_numbers(earth):
         assert not np.isnan(mean).any(), name
         floor, err = rmse(a, b), rmse(quantise_image(mean), a)
         assert err <= 0.5 * floor, (name, err, floor)
+
+
+def _decode_png(data):
+    """Minimal PNG reader for 8-bit RGB without interlace: returns (width, height, rgb bytes); checks every CRC."""
+    import struct
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, head = 8, b"", None
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body)
+        if kind == b"IHDR":
+            head = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat += body
+        at += 12 + n
+    w, h, depth, colour, _, filt, interlace = head
+    assert (depth, colour, filt, interlace) == (8, 2, 0, 0)
+    raw = zlib.decompress(idat)          # checks the Adler-32 of the stored blocks
+    rows = [raw[y * (3 * w + 1):(y + 1) * (3 * w + 1)] for y in range(h)]
+    assert all(r[0] == 0 for r in rows)  # filter type None on every scanline
+    return w, h, b"".join(r[1:] for r in rows)
+
+
+def test_image_writers(tmp_path):
+    """write_png / write_ppm, which stand in for ImageBuffer::from_raw(..).save("test.png") of the examples (cornell.rs:109-116).
+    The PNG is large enough to need more than one stored deflate block (65 535 bytes each)."""
+    host = _abi.host_lib()
+    rng = np.random.default_rng(5)
+    for w, h in [(5, 3), (1, 1), (211, 173)]:
+        px = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for ext in ("png", "ppm"):
+            path = str(tmp_path / f"img_{w}x{h}.{ext}")
+            assert host.rth_write_image(path.encode(), w, h, px.ctypes.data) == 0
+            data = open(path, "rb").read()
+            if ext == "png":
+                assert _decode_png(data) == (w, h, px.tobytes())
+            else:
+                assert data == b"P6\n%d %d\n255\n" % (w, h) + px.tobytes()
+                assert np.array_equal(rt.load_ppm(path), px)
+    assert host.rth_write_image(b"/nonexistent-dir/x.png", 1, 1, px.ctypes.data) != 0
+
+
+def test_example_driver_is_built_and_refuses_to_run_without_a_gpu():
+    """examples/rt_example (the reference's five example programs as one driver): usage errors exit with 2; on a machine
+    without a HIP device a render exits with 1 and says so -- there is no CPU path to fall back to."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "rt_example")
+    assert os.path.exists(exe), "run `make -C raytracing_amd/csrc`"
+    if _abi.hip_lib().rt_device_count() == 0:  # (no child processes from a test process that may hold a GPU)
+        assert subprocess.run([exe], capture_output=True).returncode == 2
+        assert subprocess.run([exe, "teapot"], capture_output=True).returncode == 2
+        r = subprocess.run([exe, "cornell", "--width", "8", "--spp", "1", "--out", "/dev/null"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr
