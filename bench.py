@@ -11,7 +11,10 @@ workspace and fix the point where the tail kernel takes over).
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (BVH traversal) against the
 fp32 vector peak: algorithmic flops per path segment are counted by the CPU oracle on the
 reference's traversal order (per-operation constants below) and divided by the kernel's average
-launch duration, measured here with HIP events.  `cpu_baseline` is the CPU oracle (an f64
+launch duration, measured here with HIP events in a profiled render after the timed one.  The
+timed render overlaps the traversal of one half of a pass with the shading of the other half on
+two streams; the profiled render (like --one-stream) runs the kernels one after the other, which
+is the duration a kernel trace of `bench.py --one-stream` shows.  `cpu_baseline` is the CPU oracle (an f64
 restatement of the reference, not the Rust binary) timed on this host on a bounded sample.
 """
 import argparse
@@ -87,6 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of a timed step (default: the BASELINE configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="render every pass as one half on one stream (RT_RENDER_ONE_STREAM): kernels do not "
+                    "overlap, so a kernel trace shows the per-kernel durations that the roofline is quoted on")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,12 +115,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    flags = _abi.RT_RENDER_ONE_STREAM if args.one_stream else 0
     for _ in range(args.warmup):
-        render_distributed(scene, cam, io_warm, seed=1)
+        render_distributed(scene, cam, io_warm, seed=1, flags=flags)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rgb, mean = render_distributed(scene, cam, io, seed=1)
+        rgb, mean = render_distributed(scene, cam, io, seed=1, flags=flags)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -207,7 +207,8 @@ enum {
     RT_RENDER_PROFILE = 1u,  /* time every kernel launch with HIP events (rt_get_profile) */
     RT_RENDER_NO_TAIL = 2u,  /* every bounce as separate traverse / shade launches (same image; for tests) */
     RT_RENDER_TAIL_ONLY = 4u, /* every path runs start to end in the tail kernel (same image; for tests) */
-    RT_RENDER_NODES_IN_GLOBAL = 8u /* walk the BVH in global memory even when it would fit in LDS (same image; for tests) */
+    RT_RENDER_NODES_IN_GLOBAL = 8u, /* walk the BVH in global memory even when it would fit in LDS (same image; for tests) */
+    RT_RENDER_ONE_STREAM = 16u /* never split a pass into two halves on two streams (same image; for tests and clean kernel timings) */
 };
 
 typedef struct rt_scene rt_scene; /* opaque */

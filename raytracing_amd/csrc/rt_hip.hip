@@ -124,7 +124,7 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #define RT_STEPS_PER_TURN 8   // node steps between two looks at the wave's state
 #endif
 template <bool NODES_IN_LDS>
-__global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
+__global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LDS ? 6 : 1) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
                                                                                    uint2* hits, uint32_t bounce) {
     extern __shared__ uint4 lds_nodes[];
     __shared__ uint32_t next_ray;
@@ -201,8 +201,10 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_traverse(
 // Workgroup size of k_shade.  Each workgroup pass ends in one atomic on the length of the next queue; at 256 threads
 // the rate of those atomics (all on one address) bounds the kernel, at 512 it runs within a few per cent of the same
 // kernel without compaction, which moves its ~100 bytes per segment at over half of the HBM peak.
+// Register budgets: k_traverse is held to 80 VGPRs (4 waves per SIMD = 320 of the 512 registers of a lane) and k_shade
+// to 96, so that one shading workgroup (2 waves per SIMD) fits beside the traversal workgroup of the pass's other half.
 #define RT_SHADE_BS 512
-__global__ void __launch_bounds__(RT_SHADE_BS) k_shade(SceneView S, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+__global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
     __shared__ uint32_t wave_cnt[RT_SHADE_BS / 64];
     __shared__ uint32_t block_base;
@@ -357,7 +359,8 @@ struct rt_scene {
     int device = 0;
     SceneView view{};
     std::vector<void*> allocs;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr, side_stream = nullptr;  // side_stream: second half of a pass (see render_impl)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool lds_attr_set = false;
     // workspace
     uint64_t ws_paths = 0, ws_pixels = 0;
@@ -489,6 +492,9 @@ void rt_scene_destroy(rt_scene* sc) {
     for (void* p : sc->allocs) (void)hipFree(p);
     for (auto& e : sc->event_pool) (void)hipEventDestroy(e);
     if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
+    if (sc->side_stream) (void)hipStreamDestroy(sc->side_stream);
+    if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
+    if (sc->ev_join) (void)hipEventDestroy(sc->ev_join);
     delete sc;
 }
 
@@ -545,7 +551,10 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     V.n_prims = D->n_prims;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sc->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("stream / event creation: ") + hipGetErrorString(e)); }
     *out = sc;
     return RT_OK;
 }
@@ -571,7 +580,7 @@ static rt_status ensure_workspace(rt_scene* sc, uint64_t n_paths, uint64_t n_pix
     if ((st = alloc((void**)&sc->values, n_paths * sizeof(float4))) != RT_OK) return st;
     if ((st = alloc((void**)&sc->accum, n_pixels * 3 * sizeof(double))) != RT_OK) return st;
     if ((st = alloc((void**)&sc->owned, n_pixels * sizeof(uint32_t))) != RT_OK) return st;
-    if ((st = alloc((void**)&sc->counts, n_counts * sizeof(uint32_t))) != RT_OK) return st;
+    if ((st = alloc((void**)&sc->counts, 2 * (size_t)n_counts * sizeof(uint32_t))) != RT_OK) return st;  // one set per half pass
     HIP_TRY(hipHostMalloc((void**)&sc->h_counts, n_counts * sizeof(uint32_t), hipHostMallocDefault));
     sc->ws_paths = n_paths; sc->ws_pixels = n_pixels; sc->n_counts = n_counts;
     return RT_OK;
@@ -685,39 +694,84 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
 
     const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;
     int tail_from = force_tail ? 0 : -1;  // bounce at which k_tail takes over; -1 = not calibrated yet
+    bool split_pays = false;               // set by the calibrating pass: traversal dominates shading
+
+    // A pass runs as one or two independent halves (its samples split in two), each with its own queues and counters:
+    // traversal is bound by instruction issue and shading by memory traffic, so the two halves, launched on two streams,
+    // fill each other's gaps (the shading waves of one fit beside the traversal workgroup of the other on a CU).
+    // Passes that read queue lengths back (the first, profiled ones, RT_RENDER_NO_TAIL) run as one half on one stream.
+    struct Half {
+        hipStream_t stream; PassParams P; RayQueue q[2]; uint2* hits; uint32_t* counts; float4* values; int cur;
+    };
+    auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
+        if (nodes_in_lds)
+            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+        else
+            hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+    };
+    auto launch_tail = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
+        if (nodes_in_lds)
+            hipLaunchKernelGGL(k_tail<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values,
+                               h.counts + depth + 1, b);
+        else
+            hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(RT_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values, h.counts + depth + 1, b);
+    };
     // max_reflections == 0: ray_color's loop body never runs and every sample is black (lib.rs:89, :103)
     for (uint64_t s0 = 0; s0 < spp && depth > 0; s0 += S) {
         const uint32_t ns = (uint32_t)std::min<uint64_t>(S, spp - s0);
-        P.sample_base = (uint32_t)s0; P.n_paths = ns * n_owned;
-        const uint32_t grid_full = (P.n_paths + RT_BS - 1) / RT_BS;
-        const uint32_t grid = std::min(grid_full, max_grid);
-        const uint32_t shade_grid = std::min((P.n_paths + RT_SHADE_BS - 1) / RT_SHADE_BS, max_grid * RT_BS / RT_SHADE_BS);
-        const uint32_t trav_grid = std::min((P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, (uint32_t)prop.multiProcessorCount);
-        if ((st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
-        hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, stream, P, sc->q[0], sc->counts, n_counts);
-        if ((st = L.end(ev)) != RT_OK) return st;
-        sc->prof.samples += P.n_paths; sc->prof.passes += 1;
-        int cur = 0;
         // Queue lengths are read back (one sync per bounce) only while the hand-over point to k_tail is
         // still unknown, when profiling, or when k_tail is disabled; otherwise nothing waits on the host.
         const bool readback = tail_from < 0 || profile || force_wavefront;
+        const bool calibrating = tail_from < 0 && !profile;  // this pass also times its kernels, to see whether splitting later passes pays
+        L.profile = profile || calibrating;
+        const int n_halves = (!readback && split_pays && ns >= 2 && !(ro->flags & RT_RENDER_ONE_STREAM)) ? 2 : 1;
+        Half half[2];
+        uint32_t sample_off = 0;
+        for (int k = 0; k < n_halves; ++k) {
+            Half& h = half[k];
+            const uint32_t ns_k = n_halves == 1 ? ns : (k == 0 ? (ns + 1) / 2 : ns / 2);
+            const size_t path_off = (size_t)sample_off * n_owned;
+            h.stream = k == 0 ? stream : sc->side_stream;
+            h.P = P; h.P.sample_base = (uint32_t)s0 + sample_off; h.P.n_paths = ns_k * n_owned;
+            for (int j = 0; j < 2; ++j) { h.q[j].od0 = sc->q[j].od0 + path_off; h.q[j].od1 = sc->q[j].od1 + path_off; h.q[j].thr = sc->q[j].thr + path_off; }
+            h.hits = sc->hits + path_off; h.counts = sc->counts + (size_t)k * n_counts; h.values = sc->values + path_off; h.cur = 0;
+            sample_off += ns_k;
+        }
+        if (n_halves == 2) {  // the second stream starts after everything queued so far (the previous pass's resolve reads `values`)
+            HIP_TRY(hipEventRecord(sc->ev_fork, stream));
+            HIP_TRY(hipStreamWaitEvent(sc->side_stream, sc->ev_fork, 0));
+        }
+        uint32_t grid[2], shade_grid[2], trav_grid[2];
+        for (int k = 0; k < n_halves; ++k) {
+            Half& h = half[k];
+            const uint32_t grid_full = (h.P.n_paths + RT_BS - 1) / RT_BS;
+            grid[k] = std::min(grid_full, max_grid);
+            shade_grid[k] = std::min((h.P.n_paths + RT_SHADE_BS - 1) / RT_SHADE_BS, max_grid * RT_BS / RT_SHADE_BS);
+            trav_grid[k] = std::min((h.P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, (uint32_t)prop.multiProcessorCount);
+            if (k == 0 && (st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
+            hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, h.stream, h.P, h.q[0], h.counts, n_counts);
+            if (k == 0 && (st = L.end(ev)) != RT_OK) return st;
+            sc->prof.samples += h.P.n_paths;
+        }
+        sc->prof.passes += 1;
         uint32_t b = 0;
         bool finished = false;
         for (; b < depth; ++b) {
             if (tail_from >= 0 && !force_wavefront && (int)b >= tail_from) break;
-            if ((st = L.begin(RT_K_TRAVERSE, &ev)) != RT_OK) return st;
-            if (nodes_in_lds)
-                hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->hits, b);
-            else
-                hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->hits, b);
-            if ((st = L.end(ev)) != RT_OK) return st;
-            if ((st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
-            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(RT_SHADE_BS), 0, stream, sc->view, P, sc->q[cur], sc->hits, sc->q[cur ^ 1], sc->counts + b,
-                               sc->counts + b + 1, sc->values, b);
-            if ((st = L.end(ev)) != RT_OK) return st;
-            cur ^= 1;
+            for (int k = 0; k < n_halves; ++k) {  // (event timing only in one-half passes: L works on `stream`)
+                Half& h = half[k];
+                if (n_halves == 1 && (st = L.begin(RT_K_TRAVERSE, &ev)) != RT_OK) return st;
+                launch_traverse(h, b, grid[k], trav_grid[k]);
+                if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
+                if (n_halves == 1 && (st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
+                hipLaunchKernelGGL(k_shade, dim3(shade_grid[k]), dim3(RT_SHADE_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b,
+                                   h.counts + b + 1, h.values, b);
+                if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
+                h.cur ^= 1;
+            }
+            HIP_TRY(hipGetLastError());
             if (readback) {
-                HIP_TRY(hipMemcpyAsync(sc->h_counts, sc->counts + b, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(sc->h_counts, half[0].counts + b, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 sc->prof.segments += sc->h_counts[0]; sc->prof.traverse_segments += sc->h_counts[0];
                 if (sc->h_counts[1] == 0) { finished = true; break; }
@@ -726,24 +780,37 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         }
         if (tail_from < 0 && !force_wavefront) tail_from = (int)depth;
         if (!finished && b < depth) {
-            if ((st = L.begin(RT_K_TAIL, &ev)) != RT_OK) return st;
-            if (nodes_in_lds)
-                hipLaunchKernelGGL(k_tail<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->values,
-                                   sc->counts + depth + 1, b);
-            else
-                hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(RT_BS), 0, stream, sc->view, P, sc->q[cur], sc->counts + b, sc->values,
-                                   sc->counts + depth + 1, b);
-            if ((st = L.end(ev)) != RT_OK) return st;
+            for (int k = 0; k < n_halves; ++k) {
+                if (n_halves == 1 && (st = L.begin(RT_K_TAIL, &ev)) != RT_OK) return st;
+                launch_tail(half[k], b, grid[k], trav_grid[k]);
+                if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
+            }
+            HIP_TRY(hipGetLastError());
             if (profile) {
-                HIP_TRY(hipMemcpyAsync(sc->h_counts, sc->counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(sc->h_counts, half[0].counts + depth + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 sc->prof.segments += sc->h_counts[0];
             }
         }
+        if (n_halves == 2) {  // both halves' values are complete before the per-pixel sums
+            HIP_TRY(hipEventRecord(sc->ev_join, sc->side_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join, 0));
+        }
         if ((st = L.begin(RT_K_RESOLVE, &ev)) != RT_OK) return st;
         hipLaunchKernelGGL(k_resolve, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, sc->values, sc->accum, n_owned, ns);
         if ((st = L.end(ev)) != RT_OK) return st;
+        if (calibrating) {
+            // Two halves on two streams pay when the instruction-bound traversal dominates the memory-bound shading (they
+            // then fill each other's gaps); with small trees both kernels wait on the same queue traffic and splitting
+            // only halves the work per launch.
+            HIP_TRY(hipStreamSynchronize(stream));
+            const rt_profile keep = sc->prof;
+            if ((st = collect_profile(sc)) != RT_OK) return st;
+            split_pays = sc->prof.kernel_ms[RT_K_TRAVERSE] - keep.kernel_ms[RT_K_TRAVERSE] > 1.5 * (sc->prof.kernel_ms[RT_K_SHADE] - keep.kernel_ms[RT_K_SHADE]);
+            sc->prof = keep;
+        }
     }
+    L.profile = profile;
     if ((st = L.begin(RT_K_FINALIZE, &ev)) != RT_OK) return st;
     hipLaunchKernelGGL(k_finalize, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, sc->accum, sc->owned, n_owned, W, H, (double)spp, d_mean_out);
     if ((st = L.end(ev)) != RT_OK) return st;

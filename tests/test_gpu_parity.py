@@ -125,7 +125,8 @@ def test_result_does_not_depend_on_passes_kernel_split_or_ranks(earth):
         _, base = sc.render(cam, io, rt.RenderOptions(seed=3), want_mean=True)
         for ro in (rt.RenderOptions(seed=3, samples_per_pass=5), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_NO_TAIL),
                    rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_TAIL_ONLY), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_PROFILE),
-                   rt.RenderOptions(seed=3, tile_w=8, tile_h=4)):
+                   rt.RenderOptions(seed=3, tile_w=8, tile_h=4), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_ONE_STREAM),
+                   rt.RenderOptions(seed=3, samples_per_pass=5, flags=_abi.RT_RENDER_ONE_STREAM)):
             _, m = sc.render(cam, io, ro, want_mean=True)
             assert np.array_equal(m, base), (name, ro)
         for world in (2, 4, 8):
