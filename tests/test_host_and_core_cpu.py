@@ -295,3 +295,86 @@ def test_example_driver_is_built_and_refuses_to_run_without_a_gpu():
         assert subprocess.run([exe, "teapot"], capture_output=True).returncode == 2
         r = subprocess.run([exe, "cornell", "--width", "8", "--spp", "1", "--out", "/dev/null"], capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def _walk_nodes(sc):
+    """The library's own node array for a host scene (rt::make_walk_nodes through the CPU twin): a structured array of
+    32-byte slots {x0, x1, y0, y1, z0, z1, skip, prim}, the last one being the sentinel."""
+    tw = twin()
+    desc = sc._host.rth_scene_desc(sc._h)
+    n = tw.twin_walk_nodes(desc, None, 0)
+    raw = np.zeros((n, 8), dtype=np.uint32)
+    assert tw.twin_walk_nodes(desc, raw.ctypes.data, n) == n
+    return raw
+
+
+def test_walk_node_array_keeps_the_reference_leaf_order(earth):
+    """The node array the kernels walk (pruned inner nodes, paired bounds, payload slots, sentinel): same leaves in the same
+    order as the tree that crosses the ABI, nested subtrees, inner boxes containing everything below them, fewer nodes."""
+    PRIM_MASK, PLAIN_BOX, PLAIN_SPHERE = 0x1FFFFFFF, 0x40000000, 0x20000000
+    for name in EXAMPLES:
+        sc, _ = _example(name, earth)
+        d = sc.desc
+        raw = _walk_nodes(sc)
+        f = raw[:, :6].view(np.float32)
+        skip, prim = raw[:, 6], raw[:, 7]
+        n = len(raw) - 1
+        assert skip[n] == n and prim[n] == _abi.RT_BVH_NONE            # sentinel
+        is_payload = np.zeros(n + 1, bool)
+        leaves, i = [], 0
+        while i < n:                                                     # every slot is a node or the payload of the sphere leaf before it
+            if prim[i] != _abi.RT_BVH_NONE:
+                leaves.append(int(prim[i] & PRIM_MASK))
+                P = d.prims[leaves[-1]]
+                if prim[i] & PLAIN_SPHERE:
+                    assert P.geom == _abi.RT_GEOM_SPHERE and not (P.flags & _abi.RT_PRIM_MEDIUM)
+                    is_payload[i + 1] = True
+                    c = raw[i + 1].view(np.float64)
+                    sp = d.spheres[P.geom_index]
+                    assert c[3] == sp.radius
+                    if P.xf_count == 0:
+                        assert list(c[:3]) == list(sp.center)
+                    assert skip[i] == i + 2
+                    i += 1
+                else:
+                    assert skip[i] == i + 1
+                if prim[i - int(is_payload[i])] & PLAIN_BOX:
+                    assert P.geom == _abi.RT_GEOM_BOX and P.xf_count == 0
+            i += 1
+        assert leaves == [d.bvh[k].prim & PRIM_MASK for k in range(d.n_bvh_nodes) if d.bvh[k].prim != _abi.RT_BVH_NONE]
+        nodes = [k for k in range(n) if not is_payload[k]]
+        assert len(nodes) <= d.n_bvh_nodes
+        if name == "final_scene":
+            assert len(nodes) < 0.8 * d.n_bvh_nodes                     # 2 815 -> 2 077
+        for k in nodes:
+            assert k < skip[k] <= n
+            inside = [j for j in range(k + 1, skip[k]) if not is_payload[j]]
+            if inside:
+                assert prim[k] == _abi.RT_BVH_NONE
+                assert max(skip[j] for j in inside) <= skip[k]
+                sub = f[inside]
+                assert (f[k, 0::2] <= sub[:, 0::2].min(axis=0)).all() and (f[k, 1::2] >= sub[:, 1::2].max(axis=0)).all()
+
+
+def test_wrapped_sphere_leaves_carry_the_centre_in_the_outer_frame():
+    """A Sphere behind Translated / Rotated wrappers is tested as a sphere around the wrapped centre carried out through the
+    wrappers (rotations keep lengths): the payload slot holds that centre, and hits agree with the oracle's frame-by-frame
+    evaluation (shape.rs:356-384) to the hit-record tolerance."""
+    shape = rt.Shape.Sphere((3.0, 1.0, -2.0), 1.5).rotated(1, 30.0).translated((10.0, -4.0, 7.0)).rotated(0, -70.0)
+    sc = rt.Scene([rt.Object(shape, rt.Material.Lambertian(rt.Texture.SolidColor((0.5, 0.5, 0.5))))], (0, 0, 0))
+    raw = _walk_nodes(sc)
+    k = [i for i in range(len(raw) - 1) if raw[i, 7] != _abi.RT_BVH_NONE and (raw[i, 7] & 0x1FFFFFFF) == 0][0]
+    c = raw[k + 1].view(np.float64)
+    p = np.array([3.0, 1.0, -2.0])
+    a = np.radians(30.0); p = np.array([p[2] * np.sin(a) + p[0] * np.cos(a), p[1], p[2] * np.cos(a) - p[0] * np.sin(a)])   # rotate Y (geometry.rs:33-50)
+    p = p + [10.0, -4.0, 7.0]
+    a = np.radians(-70.0); p = np.array([p[0], p[1] * np.cos(a) - p[2] * np.sin(a), p[1] * np.sin(a) + p[2] * np.cos(a)])  # rotate X
+    assert np.allclose(c[:3], p, rtol=0, atol=1e-12) and c[3] == 1.5
+    osh = OracleShape(shape)
+    rng = np.random.default_rng(11)
+    mn, mx = osh.bound()
+    o, dd, t = rays_at_box(rng, mn, mx, 4000)
+    ref = osh.intersect(o, dd, t, 0.001, float("inf"))
+    got = twin_intersect(sc, o, dd, t)
+    nsame, _ = compare_hits(got, ref, "wrapped sphere", allow_flag_mismatch=2e-3, origins=o)
+    assert nsame > 500

@@ -3,6 +3,7 @@
 // host loops, so that intersection / shading / camera logic can be unit-tested against
 // the oracle on a machine without a GPU.  Nothing in the product loads this library.
 
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <thread>
@@ -97,6 +98,16 @@ void twin_traverse_stats(const rt_scene_desc* D, const rt_ray* rays, uint64_t n,
         closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);
         out[3 * i] = (uint32_t)g_tc.nodes; out[3 * i + 1] = (uint32_t)g_tc.leaves; out[3 * i + 2] = (uint32_t)g_tc.prim_tests;
     }
+}
+
+// The walk's node array as the library builds it from a scene description (rt::make_walk_nodes): returns the number of
+// slots including the sentinel and copies up to `cap` of them (8 x uint32 per slot) to `out`.
+uint32_t twin_walk_nodes(const rt_scene_desc* D, uint32_t* out, uint32_t cap) {
+    std::vector<WalkNode> nodes;
+    make_walk_nodes(D, nodes);
+    const size_t n = std::min<size_t>(nodes.size(), cap);
+    if (out && n) std::memcpy(out, nodes.data(), n * sizeof(WalkNode));
+    return (uint32_t)nodes.size();
 }
 
 // What-if analysis: the same walk with up to `defer` leaves left pending (their primitive tests run, in order, only when
