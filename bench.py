@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel of a timed step (default: the BASELINE configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="N > 1 ranks that all use GPU 0 and gather over gloo (functional rehearsal only)")
     ap.add_argument("--one-stream", action="store_true", help="render every pass as one half on one stream (RT_RENDER_ONE_STREAM): kernels do not "
                     "overlap, so a kernel trace shows the per-kernel durations that the roofline is quoted on")
     args = ap.parse_args()
@@ -97,9 +98,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0  # every rank on GPU 0, frames gathered over gloo: exercises the N > 1 path on a one-GPU box (not a measurement)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     earth = rt.earthmap()
@@ -125,7 +131,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

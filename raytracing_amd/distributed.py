@@ -29,7 +29,10 @@ def owned_mask(width, height, rank, world_size, tile_w=TILE_W, tile_h=TILE_H):
 def gather_frames(local_mean: torch.Tensor, dst: int = 0, group=None) -> torch.Tensor:
     """Sum-reduce of the per-rank frames (zeros outside the owned tiles) to `dst`; in place."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(local_mean, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if local_mean.is_cuda and dist.get_backend(group) == "gloo":
+            dist.all_reduce(local_mean, op=dist.ReduceOp.SUM, group=group)  # gloo has no reduce() for device tensors (rehearsals only)
+        else:
+            dist.reduce(local_mean, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return local_mean
 
 
