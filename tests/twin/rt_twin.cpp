@@ -100,6 +100,50 @@ void twin_traverse_stats(const rt_scene_desc* D, const rt_ray* rays, uint64_t n,
     }
 }
 
+// What-if analysis: node tests per ray if the reference's binary tree were walked nearer child first (NOT result-neutral
+// for this crate; only to see what the fixed leaf order costs).  out: node tests per ray.
+void twin_traverse_ordered(const rt_scene_desc* D, const rt_ray* rays, uint64_t n, uint32_t* out) {
+    const TwinScene scene(D); const SceneView& S = scene.V;
+    const rt_bvh_node* T = D->bvh;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r; r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]); r.time = rays[i].time;
+        DrawKey key; key.k0 = 1; key.k1 = 0; key.pixel = (uint32_t)i; key.sample = 0; key.bounce = 0; key.medium_u = -1.0f;
+        const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        float tmax = RT_INF_F; uint32_t nodes = 0;
+        auto entry = [&](uint32_t k, float& tn) {
+            ++nodes;
+            const rt_bvh_node& N = T[k];
+            float x0 = (N.min[0] - r.o.x) * inv.x, x1 = (N.max[0] - r.o.x) * inv.x, y0 = (N.min[1] - r.o.y) * inv.y, y1 = (N.max[1] - r.o.y) * inv.y;
+            float z0 = (N.min[2] - r.o.z) * inv.z, z1 = (N.max[2] - r.o.z) * inv.z;
+            tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.001f));
+            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+            return tn <= tf;
+        };
+        uint32_t stack[128]; float stack_t[128]; int sp = 0;
+        float t0;
+        if (D->n_bvh_nodes && entry(0, t0)) { stack[sp] = 0; stack_t[sp++] = t0; }
+        while (sp) {
+            const uint32_t k = stack[--sp];
+            if (stack_t[sp] > tmax) continue;
+            if (T[k].prim != RT_BVH_NONE) {
+                float t; int side;
+                if (prim_t(S, T[k].prim & RT_NODE_PRIM_MASK, r.o, r.d, 0.001f, tmax, r.time, key, t, side)) tmax = t;
+                continue;
+            }
+            const uint32_t a = k + 1, b = T[a].skip;
+            float ta, tb;
+            const bool ha = entry(a, ta), hb = b < T[k].skip && entry(b, tb);
+            if (ha && hb) {
+                if (ta <= tb) { stack[sp] = b; stack_t[sp++] = tb; stack[sp] = a; stack_t[sp++] = ta; }
+                else { stack[sp] = a; stack_t[sp++] = ta; stack[sp] = b; stack_t[sp++] = tb; }
+            } else if (ha) { stack[sp] = a; stack_t[sp++] = ta; }
+            else if (hb) { stack[sp] = b; stack_t[sp++] = tb; }
+        }
+        out[i] = nodes;
+    }
+}
+
 // The walk's node array as the library builds it from a scene description (rt::make_walk_nodes): returns the number of
 // slots including the sentinel and copies up to `cap` of them (8 x uint32 per slot) to `out`.
 uint32_t twin_walk_nodes(const rt_scene_desc* D, uint32_t* out, uint32_t cap) {
