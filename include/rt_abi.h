@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -78,20 +78,22 @@ typedef struct rt_sphere {
     double start_time;
 } rt_sphere; /* 64 bytes */
 
-/* Rectangle { axis, lower_left, upper_right, height } (shape.rs:77-82). */
+/* Rectangle { axis, lower_left, upper_right, height } (shape.rs:77-82).  Geometry crosses the boundary in the
+ * reference's f64; the library keeps each coordinate as an fp32 value plus an fp32 remainder, so that the
+ * difference (plane - ray origin), which sets t for a ray starting close to the plane, is formed without
+ * the rounding of the plane to fp32 (1e-5 of t for grazing rays otherwise). */
 typedef struct rt_rect {
     uint32_t axis; /* 0 X, 1 Y, 2 Z: the axis orthogonal to the rectangle */
-    float x0, y0, x1, y1, height;
-    uint32_t reserved[2];
-} rt_rect; /* 32 bytes */
+    uint32_t reserved;
+    double x0, y0, x1, y1, height;
+} rt_rect; /* 48 bytes */
 
 /* Box { min, max, sides } (shape.rs:88-92); the six sides are those of
  * Shape::new_box (shape.rs:157-215), in that order. */
 typedef struct rt_box {
-    float min[3];
-    float max[3];
-    uint32_t reserved[2];
-} rt_box; /* 32 bytes */
+    double min[3];
+    double max[3];
+} rt_box; /* 48 bytes */
 
 /* One rigid wrapper: Translated { offset } (shape.rs:98) or Rotated { axis,
  * angle } (shape.rs:101-105) with cos/sin of +angle precomputed.  Kept in f64: a ray is

@@ -29,12 +29,12 @@ class rt_sphere(C.Structure):
 
 
 class rt_rect(C.Structure):
-    _fields_ = [("axis", C.c_uint32), ("x0", C.c_float), ("y0", C.c_float), ("x1", C.c_float), ("y1", C.c_float), ("height", C.c_float),
-                ("reserved", C.c_uint32 * 2)]
+    _fields_ = [("axis", C.c_uint32), ("reserved", C.c_uint32), ("x0", C.c_double), ("y0", C.c_double), ("x1", C.c_double), ("y1", C.c_double),
+                ("height", C.c_double)]
 
 
 class rt_box(C.Structure):
-    _fields_ = [("min", C.c_float * 3), ("max", C.c_float * 3), ("reserved", C.c_uint32 * 2)]
+    _fields_ = [("min", C.c_double * 3), ("max", C.c_double * 3)]
 
 
 class rt_xform(C.Structure):

@@ -381,13 +381,13 @@ void Scene::Impl::add_object(const Object& obj) {
             break;
         }
         case K::Rectangle: {
-            rt_rect r{}; r.axis = (uint32_t)cur->axis; r.x0 = (float)cur->x0; r.y0 = (float)cur->y0; r.x1 = (float)cur->x1; r.y1 = (float)cur->y1; r.height = (float)cur->height;
+            rt_rect r{}; r.axis = (uint32_t)cur->axis; r.x0 = cur->x0; r.y0 = cur->y0; r.x1 = cur->x1; r.y1 = cur->y1; r.height = cur->height;
             P.geom = RT_GEOM_RECT; P.geom_index = (uint32_t)rects.size(); rects.push_back(r);
             break;
         }
         default: {  // Box
             rt_box b{};
-            for (int c = 0; c < 3; ++c) { b.min[c] = (float)cur->bmin[c]; b.max[c] = (float)cur->bmax[c]; }
+            for (int c = 0; c < 3; ++c) { b.min[c] = cur->bmin[c]; b.max[c] = cur->bmax[c]; }
             P.geom = RT_GEOM_BOX; P.geom_index = (uint32_t)boxes.size(); boxes.push_back(b);
             break;
         }

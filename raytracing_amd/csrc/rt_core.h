@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/rt_abi.h"
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -111,12 +112,36 @@ RT_HD float medium_variate(const DrawKey& k, uint32_t prim) {
 
 // --------------------------------------------------------------- the scene
 struct SceneView {
-    const rt_prim* prims; const rt_sphere* spheres; const rt_rect* rects; const rt_box* boxes; const rt_xform* xforms;
+    const rt_prim* prims; const rt_sphere* spheres; const struct DevRect* rects; const struct DevBox* boxes; const rt_xform* xforms;  // rects, boxes: make_device_shapes
     const rt_material* materials; const rt_texture* textures; const rt_image* images; const uint8_t* texels;
     const uint8_t* perm; const struct WalkNode* bvh;  // bvh: n_bvh_nodes slots and one sentinel slot (make_walk_nodes)
     uint32_t n_prims, n_bvh_nodes;
     float background[3];
 };
+
+// Rectangles and boxes as the kernels hold them: every f64 coordinate of the description as an fp32 value `hi` and an
+// fp32 remainder `lo` (hi + lo carries 48 bits of it).  A ray that starts close to a plane gets its t from the small
+// difference (plane - origin); formed as (hi - origin) + lo that difference keeps its relative accuracy in fp32, where
+// a plane rounded to fp32 alone would cost up to 1e-5 of t.  The f64 code paths use hi + lo as the coordinate.
+struct DevRect { uint32_t axis; float x0, y0, x1, y1, h; float x0_lo, y0_lo, x1_lo, y1_lo, h_lo; uint32_t pad; };
+struct DevBox { float min[3], max[3], min_lo[3], max_lo[3]; };
+static_assert(sizeof(DevRect) == 48 && sizeof(DevBox) == 48, "device shape sizes");
+inline void split_hi_lo(double x, float& hi, float& lo) {
+    hi = (float)x;
+    lo = (hi - hi == 0.0f) ? (float)(x - (double)hi) : 0.0f;  // no remainder for infinities and NaN
+}
+// (host side) the device forms of a description's rectangles and boxes
+inline void make_device_shapes(const rt_scene_desc* D, std::vector<DevRect>& rects, std::vector<DevBox>& boxes) {
+    rects.resize(D->n_rects); boxes.resize(D->n_boxes);
+    for (uint32_t i = 0; i < D->n_rects; ++i) {
+        const rt_rect& R = D->rects[i]; DevRect& o = rects[i];
+        o.axis = R.axis; o.pad = 0;
+        split_hi_lo(R.x0, o.x0, o.x0_lo); split_hi_lo(R.y0, o.y0, o.y0_lo); split_hi_lo(R.x1, o.x1, o.x1_lo); split_hi_lo(R.y1, o.y1, o.y1_lo);
+        split_hi_lo(R.height, o.h, o.h_lo);
+    }
+    for (uint32_t i = 0; i < D->n_boxes; ++i)
+        for (int c = 0; c < 3; ++c) { split_hi_lo(D->boxes[i].min[c], boxes[i].min[c], boxes[i].min_lo[c]); split_hi_lo(D->boxes[i].max[c], boxes[i].max[c], boxes[i].max_lo[c]); }
+}
 
 RT_HD void axis_perm(uint32_t axis, int& p1, int& p2, int& o) {  // shape.rs:138-142
     if (axis == 0) { p1 = 1; p2 = 2; o = 0; } else if (axis == 1) { p1 = 2; p2 = 0; o = 1; } else { p1 = 0; p2 = 1; o = 2; }
@@ -208,10 +233,11 @@ RT_HD bool sphere_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time
 
 // Rectangle (shape.rs:309-332): inclusive interval and extents tests written so that NaN and
 // infinity flow exactly as in the reference.
+// `height_lo`: the remainder of the plane's coordinate (fp32 callers; the f64 callers pass the whole coordinate as `height`).
 template <class T, class VT>
-RT_HD bool rect_t(uint32_t axis, T x0, T y0, T x1, T y1, T height, VT o, VT d, T tmin, T tmax, T& t_out) {
+RT_HD bool rect_t(uint32_t axis, T x0, T y0, T x1, T y1, T height, T height_lo, VT o, VT d, T tmin, T tmax, T& t_out) {
     int p1, p2, oo; axis_perm(axis, p1, p2, oo);
-    T t = (height - get(o, oo)) / get(d, oo);
+    T t = ((height - get(o, oo)) + height_lo) / get(d, oo);
     if (t < tmin || t > tmax) return false;
     VT pt = ray_at(o, d, t);
     T a = get(pt, p1), b = get(pt, p2);
@@ -223,42 +249,50 @@ RT_HD bool rect_t(uint32_t axis, T x0, T y0, T x1, T y1, T height, VT o, VT d, T
 // (lower_left, upper_right) pairs in (p1, p2) order, which is (z, x) for Axis::Y (shape.rs:315-319), but
 // new_box fills the y sides with (x0, z0) / (x1, z1) (shape.rs:180-195): on those two sides the hit
 // point's z is tested against the box's x range and its x against the z range.  Reproduced as is.
-RT_HD void box_side(const rt_box& B, int k, uint32_t& axis, float& x0, float& y0, float& x1, float& y1, float& h) {
+template <class T> RT_HD T coord(float hi, float lo);
+template <> RT_HD float coord<float>(float hi, float) { return hi; }
+template <> RT_HD double coord<double>(float hi, float lo) { return (double)hi + (double)lo; }
+// (components picked with selects: indexing the arrays with a run-time side would put the box in scratch memory)
+template <class T>
+RT_HD void box_side(const DevBox& B, int k, uint32_t& axis, T& x0, T& y0, T& x1, T& y1, T& h, T& h_lo) {
     axis = (uint32_t)(k >> 1);
     int p1, p2, oo; axis_perm(axis, p1, p2, oo);
-    if (axis == 1) { x0 = B.min[0]; y0 = B.min[2]; x1 = B.max[0]; y1 = B.max[2]; }
-    else { x0 = B.min[p1]; y0 = B.min[p2]; x1 = B.max[p1]; y1 = B.max[p2]; }
-    h = (k & 1) ? B.max[oo] : B.min[oo];
+    const V3 mn = v3(B.min[0], B.min[1], B.min[2]), mx = v3(B.max[0], B.max[1], B.max[2]);
+    const V3 mnl = v3(B.min_lo[0], B.min_lo[1], B.min_lo[2]), mxl = v3(B.max_lo[0], B.max_lo[1], B.max_lo[2]);
+    if (axis == 1) p1 = 0, p2 = 2;  // the swapped extents of the y sides
+    x0 = coord<T>(comp(mn, p1), comp(mnl, p1)); y0 = coord<T>(comp(mn, p2), comp(mnl, p2));
+    x1 = coord<T>(comp(mx, p1), comp(mxl, p1)); y1 = coord<T>(comp(mx, p2), comp(mxl, p2));
+    const float hh = (k & 1) ? comp(mx, oo) : comp(mn, oo), hl = (k & 1) ? comp(mxl, oo) : comp(mnl, oo);
+    h = coord<T>(hh, hl);
+    h_lo = sizeof(T) == sizeof(float) ? (T)hl : (T)0;  // already inside h for f64
 }
 // Box = Vec<Shape>::intersect over the six sides with shrinking tmax (shape.rs:17-34):
 // the smallest accepted t wins and a later side wins an exact tie.
 template <class T, class VT>
-RT_HD bool box_t(const rt_box& B, VT o, VT d, T tmin, T tmax, T& t_out, int& side) {
+RT_HD bool box_t(const DevBox& B, VT o, VT d, T tmin, T tmax, T& t_out, int& side) {
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        uint32_t axis; float x0, y0, x1, y1, h; T t;
-        box_side(B, k, axis, x0, y0, x1, y1, h);
-        if (rect_t<T, VT>(axis, (T)x0, (T)y0, (T)x1, (T)y1, (T)h, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
+        uint32_t axis; T x0, y0, x1, y1, h, h_lo, t;
+        box_side<T>(B, k, axis, x0, y0, x1, y1, h, h_lo);
+        if (rect_t<T, VT>(axis, x0, y0, x1, y1, h, h_lo, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
     }
     return any;
 }
-// The same six sides in fp32 with the plane parameters given: q[2a + s] = (bound[s][a] - origin[a]) * (1 / direction[a]).
+// The same six sides in fp32 with the plane parameters given: q[2a + s] = ((bound[s][a] - origin[a]) + remainder) * (1 / direction[a]).
 // Every fp32 box test and every exact leaf test (closest_hit) forms its parameters by this one expression, so two
 // boxes that share a face see bit-identical t on it, which is what the reference's tie rule needs.
-RT_HD void box_quotients(const float* bmin, const float* bmax, V3 o, V3 inv, float* q) {
-    q[0] = (bmin[0] - o.x) * inv.x; q[1] = (bmax[0] - o.x) * inv.x;
-    q[2] = (bmin[1] - o.y) * inv.y; q[3] = (bmax[1] - o.y) * inv.y;
-    q[4] = (bmin[2] - o.z) * inv.z; q[5] = (bmax[2] - o.z) * inv.z;
+RT_HD void box_quotients(const DevBox& B, V3 o, V3 inv, float* q) {
+    q[0] = ((B.min[0] - o.x) + B.min_lo[0]) * inv.x; q[1] = ((B.max[0] - o.x) + B.max_lo[0]) * inv.x;
+    q[2] = ((B.min[1] - o.y) + B.min_lo[1]) * inv.y; q[3] = ((B.max[1] - o.y) + B.max_lo[1]) * inv.y;
+    q[4] = ((B.min[2] - o.z) + B.min_lo[2]) * inv.z; q[5] = ((B.max[2] - o.z) + B.max_lo[2]) * inv.z;
 }
-RT_HD bool box_sides_q(const float* bmin, const float* bmax, V3 o, V3 d, const float* q, float tmin, float tmax, float& t_out, int& side) {
+RT_HD bool box_sides_q(const DevBox& B, V3 o, V3 d, const float* q, float tmin, float tmax, float& t_out, int& side) {
     bool any = false;
-    rt_box B;
-    B.min[0] = bmin[0]; B.min[1] = bmin[1]; B.min[2] = bmin[2]; B.max[0] = bmax[0]; B.max[1] = bmax[1]; B.max[2] = bmax[2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        uint32_t axis; float x0, y0, x1, y1, h;
-        box_side(B, k, axis, x0, y0, x1, y1, h);
+        uint32_t axis; float x0, y0, x1, y1, h, h_lo;
+        box_side<float>(B, k, axis, x0, y0, x1, y1, h, h_lo);
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
         const float t = q[k];
         if (t < tmin || t > tmax) continue;
@@ -270,11 +304,11 @@ RT_HD bool box_sides_q(const float* bmin, const float* bmax, V3 o, V3 d, const f
     return any;
 }
 template <>
-RT_HD bool box_t<float, V3>(const rt_box& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) {
+RT_HD bool box_t<float, V3>(const DevBox& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) {
     const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float q[6];
-    box_quotients(B.min, B.max, o, inv, q);
-    return box_sides_q(B.min, B.max, o, d, q, tmin, tmax, t_out, side);
+    box_quotients(B, o, inv, q);
+    return box_sides_q(B, o, d, q, tmin, tmax, t_out, side);
 }
 
 // Ray parameter of the innermost shape for a ray already in its frame.
@@ -289,8 +323,9 @@ RT_HD bool geom_t(const SceneView& S, const rt_prim& P, VT o, VT d, T tmin, T tm
         return true;
     }
     if (P.geom == RT_GEOM_RECT) {
-        const rt_rect R = S.rects[P.geom_index];
-        return rect_t<T, VT>(R.axis, (T)R.x0, (T)R.y0, (T)R.x1, (T)R.y1, (T)R.height, o, d, tmin, tmax, t);
+        const DevRect R = S.rects[P.geom_index];
+        return rect_t<T, VT>(R.axis, coord<T>(R.x0, R.x0_lo), coord<T>(R.y0, R.y0_lo), coord<T>(R.x1, R.x1_lo), coord<T>(R.y1, R.y1_lo), coord<T>(R.h, R.h_lo),
+                             sizeof(T) == sizeof(float) ? (T)R.h_lo : (T)0, o, d, tmin, tmax, t);
     }
     return box_t<T, VT>(S.boxes[P.geom_index], o, d, tmin, tmax, t, side);
 }
@@ -364,20 +399,21 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
         }
         px = p.x; py = p.y; pz = p.z;
     } else {
-        uint32_t axis; float x0, y0, x1, y1, hgt; bool flip_side = false;
+        uint32_t axis; double x0, y0, x1, y1, hgt, unused; bool flip_side = false;
         if (P.geom == RT_GEOM_RECT) {
-            const rt_rect R = S.rects[P.geom_index];
-            axis = R.axis; x0 = R.x0; y0 = R.y0; x1 = R.x1; y1 = R.y1; hgt = R.height;
+            const DevRect R = S.rects[P.geom_index];
+            axis = R.axis; x0 = coord<double>(R.x0, R.x0_lo); y0 = coord<double>(R.y0, R.y0_lo); x1 = coord<double>(R.x1, R.x1_lo); y1 = coord<double>(R.y1, R.y1_lo);
+            hgt = coord<double>(R.h, R.h_lo);
         } else {
-            box_side(S.boxes[P.geom_index], side, axis, x0, y0, x1, y1, hgt);
+            box_side<double>(S.boxes[P.geom_index], side, axis, x0, y0, x1, y1, hgt, unused);
             flip_side = (side & 1) == 0;  // the x0 / y0 / z0 sides are Flipped (outward normals)
         }
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
-        const double t64 = ((double)hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321
+        const double t64 = (hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321
         const D3 p = ray_at(o, d, t64);
         if (want_uv) {
-            uu = (compd(p, p1) - (double)x0) / ((double)x1 - (double)x0);
-            vv = (compd(p, p2) - (double)y0) / ((double)y1 - (double)y0);
+            uu = (compd(p, p1) - x0) / (x1 - x0);
+            vv = (compd(p, p2) - y0) / (y1 - y0);
         }
         const double s = flip_side ? -1.0 : 1.0;
         px = p.x; py = p.y; pz = p.z;
@@ -427,7 +463,10 @@ struct Ray {
 // The walk runs on the library's own copy of the node array (make_walk_nodes below): 32-byte slots with the bounds
 // paired per axis, the caller's leaf bits (primitive id = RT_NODE_PRIM_MASK, RT_BVH_EXACT) and two more that only say
 // where the numbers of a leaf's primitive are (the arithmetic is the same with or without them):
-//   RT_NODE_PLAIN_BOX     exact leaf whose primitive is a box without wrappers or medium: the leaf's box is the geometry;
+//   (RT_BVH_EXACT)        the array slot after an exact leaf holds its exact box {min.xyz, max.xyz} for the reference's own
+//                         box test at the leaf; the box in the node is widened like every other (it only gates the visit);
+//   RT_NODE_PLAIN_BOX     exact leaf whose primitive is a box without wrappers or medium: the leaf's exact box is the
+//                         geometry, and a second slot holds the fp32 remainders of the box's f64 coordinates (see DevBox);
 //   RT_NODE_PLAIN_SPHERE  leaf of a Sphere that is not a medium's boundary: the array slot after the leaf holds
 //                         {center.x, center.y, center.z, radius} as four doubles (the leaf's skip link jumps over it).
 //                         Behind Translated / Rotated wrappers the centre is the wrapped sphere's centre carried out
@@ -499,8 +538,28 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
         const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
         return Pp.geom == RT_GEOM_SPHERE && !(Pp.flags & RT_PRIM_MEDIUM);
     };
+    auto plain_box = [&](const rt_bvh_node& N) {  // exact leaf of an unwrapped box whose box is the leaf's box (rounded to fp32)
+        if (N.prim == RT_BVH_NONE || !(N.prim & RT_BVH_EXACT)) return false;
+        const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
+        if (Pp.geom != RT_GEOM_BOX || Pp.xf_count != 0 || (Pp.flags & RT_PRIM_MEDIUM)) return false;
+        const rt_box& B = D->boxes[Pp.geom_index];
+        bool same = true;
+        for (int c = 0; c < 3; ++c) same = same && (float)B.min[c] == N.min[c] && (float)B.max[c] == N.max[c];
+        return same;
+    };
+    auto exact_leaf = [&](const rt_bvh_node& N) { return N.prim != RT_BVH_NONE && (N.prim & RT_BVH_EXACT) != 0; };
+    auto payload_slots = [&](const rt_bvh_node& N) { return plain_sphere(N) ? 1u : (plain_box(N) ? 2u : (exact_leaf(N) ? 1u : 0u)); };
+    // exact leaves keep their exact box in a payload slot; the box in the node itself, which only decides whether the walk
+    // visits the leaf, is widened like every other node box (the fp32 slab test is accurate to ulps of origin / direction)
+    double max_abs = 0.0;
+    for (uint32_t i = 0; i < n_in; ++i)
+        for (int c = 0; c < 3; ++c) {
+            if (tree[i].min[c] - tree[i].min[c] == 0.0f) max_abs = std::fmax(max_abs, std::fabs((double)tree[i].min[c]));
+            if (tree[i].max[c] - tree[i].max[c] == 0.0f) max_abs = std::fmax(max_abs, std::fabs((double)tree[i].max[c]));
+        }
+    const double pad = std::fmax(1e-6, 4e-6 * max_abs);
     uint32_t at = 0;
-    for (uint32_t i = 0; i < n_in; ++i) { new_index[i] = at; at += plain_sphere(tree[i]) ? 2u : 1u; }
+    for (uint32_t i = 0; i < n_in; ++i) { new_index[i] = at; at += 1u + payload_slots(tree[i]); }
     new_index[n_in] = at;
     nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at, RT_BVH_NONE});
     for (uint32_t i = 0; i < n_in; ++i) {
@@ -520,11 +579,19 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
                 const double payload[4] = {c.x, c.y, c.z, sp.radius};
                 static_assert(sizeof(payload) == sizeof(WalkNode), "payload slot size");
                 std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
-            } else if ((N.prim & RT_BVH_EXACT) && Pp.geom == RT_GEOM_BOX && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM)) {
-                const rt_box& B = D->boxes[Pp.geom_index];
-                bool same = true;
-                for (int c = 0; c < 3; ++c) same = same && B.min[c] == N.min[c] && B.max[c] == N.max[c];
-                if (same) W.prim |= RT_NODE_PLAIN_BOX;
+            } else if (exact_leaf(N)) {
+                const float exact[8] = {N.min[0], N.min[1], N.min[2], N.max[0], N.max[1], N.max[2], 0.0f, 0.0f};
+                std::memcpy(&nodes[new_index[i] + 1], exact, sizeof(exact));
+                if (plain_box(N)) {
+                    W.prim |= RT_NODE_PLAIN_BOX;
+                    const rt_box& B = D->boxes[Pp.geom_index];
+                    float rem[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, hi;
+                    for (int c = 0; c < 3; ++c) { split_hi_lo(B.min[c], hi, rem[c]); split_hi_lo(B.max[c], hi, rem[3 + c]); }
+                    std::memcpy(&nodes[new_index[i] + 2], rem, sizeof(rem));
+                }
+                auto down = [&](float x) { float f = (float)((double)x - pad); while ((double)f > (double)x - pad) f = std::nextafterf(f, -INFINITY); return f; };
+                auto up = [&](float x) { float f = (float)((double)x + pad); while ((double)f < (double)x + pad) f = std::nextafterf(f, INFINITY); return f; };
+                W.x0 = down(N.min[0]); W.x1 = up(N.max[0]); W.y0 = down(N.min[1]); W.y1 = up(N.max[1]); W.z0 = down(N.min[2]); W.z1 = up(N.max[2]);
             }
         }
         nodes[new_index[i]] = W;
@@ -604,10 +671,13 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, 
     if (!(leaf & RT_BVH_EXACT)) return false;
     // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: (bound - origin) over the direction,
     // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
-    const WalkNode N = S.bvh[w.leaf_node];
-    const float bmin[3] = {N.x0, N.y0, N.z0}, bmax[3] = {N.x1, N.y1, N.z1};
+    const bool plain = (leaf & RT_NODE_PLAIN_BOX) != 0;
+    const float* exact = reinterpret_cast<const float*>(&S.bvh[w.leaf_node + 1]);
+    const float* rem = reinterpret_cast<const float*>(&S.bvh[w.leaf_node + (plain ? 2u : 1u)]);  // the remainders; any slot when unused
+    DevBox B;
+    for (int c = 0; c < 3; ++c) { B.min[c] = exact[c]; B.max[c] = exact[3 + c]; B.min_lo[c] = plain ? rem[c] : 0.0f; B.max_lo[c] = plain ? rem[3 + c] : 0.0f; }
     float q[6];
-    box_quotients(bmin, bmax, r.o, inv, q);
+    box_quotients(B, r.o, inv, q);
     float lo = tmin, hi = w.tmax;
     lo = fmaxf(r.d.x < 0.0f ? q[1] : q[0], lo); hi = fminf(r.d.x < 0.0f ? q[0] : q[1], hi);
     bool enter = !(hi <= lo);
@@ -616,15 +686,10 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, 
     lo = fmaxf(r.d.z < 0.0f ? q[5] : q[4], lo); hi = fminf(r.d.z < 0.0f ? q[4] : q[5], hi);
     enter = enter && !(hi <= lo);
     if (!enter) { RT_COUNT(leaves); return true; }
-    bool plain = (leaf & RT_NODE_PLAIN_BOX) != 0;
-    if (!plain) {
-        const rt_prim P = S.prims[prim];
-        plain = P.geom == RT_GEOM_BOX && P.xf_count == 0 && !(P.flags & RT_PRIM_MEDIUM);
-    }
     if (!plain) return false;
     RT_COUNT(leaves); RT_COUNT(prim_tests);
     float t; int side;  // the leaf's box is the box: same arithmetic as box_t<float>, without fetching it
-    if (box_sides_q(bmin, bmax, r.o, r.d, q, tmin, w.tmax, t, side)) walk_accept(w, t, prim, side);
+    if (box_sides_q(B, r.o, r.d, q, tmin, w.tmax, t, side)) walk_accept(w, t, prim, side);
     return true;
 }
 // Everything else: the general Intersection::intersect.  (An exact leaf arrives here only after walk_leaf_fast

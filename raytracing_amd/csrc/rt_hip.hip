@@ -514,8 +514,12 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
 #define UP(field, src, n) do { st = upload(sc, src, (size_t)(n), &V.field); if (st != RT_OK) { rt_scene_destroy(sc); return st; } } while (0)
     UP(prims, D->prims, D->n_prims);
     UP(spheres, D->spheres, D->n_spheres);
-    UP(rects, D->rects, D->n_rects);
-    UP(boxes, D->boxes, D->n_boxes);
+    {   // rectangles and boxes in the kernels' own form (fp32 value + fp32 remainder per f64 coordinate)
+        std::vector<DevRect> rects; std::vector<DevBox> boxes;
+        make_device_shapes(D, rects, boxes);
+        UP(rects, rects.data(), rects.size());
+        UP(boxes, boxes.data(), boxes.size());
+    }
     UP(xforms, D->xforms, D->n_xforms);
     {   // materials, with RT_MAT_SKIP_UV where no reachable texture is an image (the only kind that reads (u, v))
         std::vector<rt_material> mats(D->materials, D->materials + D->n_materials);

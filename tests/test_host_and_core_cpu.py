@@ -32,12 +32,12 @@ def test_abi_header_symbols_are_exported():
     lib = _abi.hip_lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == 2
     _abi.host_lib()
 
 
 def test_struct_sizes_match_the_header():
-    sizes = {_abi.rt_prim: 32, _abi.rt_sphere: 64, _abi.rt_rect: 32, _abi.rt_box: 32, _abi.rt_xform: 32, _abi.rt_material: 32, _abi.rt_texture: 32,
+    sizes = {_abi.rt_prim: 32, _abi.rt_sphere: 64, _abi.rt_rect: 48, _abi.rt_box: 48, _abi.rt_xform: 32, _abi.rt_material: 32, _abi.rt_texture: 32,
              _abi.rt_image: 16, _abi.rt_bvh_node: 32, _abi.rt_ray: 28, _abi.rt_hit: 56, _abi.rt_camera: 168}
     for t, n in sizes.items():
         assert C.sizeof(t) == n, t
@@ -320,7 +320,8 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
         skip, prim = raw[:, 6], raw[:, 7]
         n = len(raw) - 1
         assert skip[n] == n and prim[n] == _abi.RT_BVH_NONE            # sentinel
-        is_payload = np.zeros(n + 1, bool)
+        is_payload = np.zeros(n + 2, bool)
+        tight = f.copy()   # the boxes that have to nest: a node's own box, for exact leaves the exact box of the payload slot
         leaves, i = [], 0
         while i < n:                                                     # every slot is a node or the payload of the sphere leaf before it
             if prim[i] != _abi.RT_BVH_NONE:
@@ -336,10 +337,25 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
                         assert list(c[:3]) == list(sp.center)
                     assert skip[i] == i + 2
                     i += 1
+                elif prim[i] & _abi.RT_BVH_EXACT:
+                    # exact leaves: the exact box in the next slot, inside the (widened) box of the node itself
+                    is_payload[i + 1] = True
+                    ex = raw[i + 1, :6].view(np.float32)
+                    assert (f[i, 0::2] < ex[:3]).all() and (f[i, 1::2] > ex[3:]).all()
+                    tight[i, 0::2], tight[i, 1::2] = ex[:3], ex[3:]
+                    n_slots = 1
+                    if prim[i] & PLAIN_BOX:
+                        assert P.geom == _abi.RT_GEOM_BOX and P.xf_count == 0
+                        is_payload[i + 2] = True
+                        n_slots = 2
+                        bx = d.boxes[P.geom_index]
+                        full = ex.astype(np.float64) + raw[i + 2, :6].view(np.float32).astype(np.float64)   # value + remainder
+                        assert np.allclose(full, list(bx.min) + list(bx.max), rtol=2e-14, atol=0)
+                    assert skip[i] == i + 1 + n_slots
+                    i += n_slots
                 else:
+                    assert not (prim[i] & PLAIN_BOX)
                     assert skip[i] == i + 1
-                if prim[i - int(is_payload[i])] & PLAIN_BOX:
-                    assert P.geom == _abi.RT_GEOM_BOX and P.xf_count == 0
             i += 1
         assert leaves == [d.bvh[k].prim & PRIM_MASK for k in range(d.n_bvh_nodes) if d.bvh[k].prim != _abi.RT_BVH_NONE]
         nodes = [k for k in range(n) if not is_payload[k]]
@@ -352,7 +368,7 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
             if inside:
                 assert prim[k] == _abi.RT_BVH_NONE
                 assert max(skip[j] for j in inside) <= skip[k]
-                sub = f[inside]
+                sub = tight[inside]
                 assert (f[k, 0::2] <= sub[:, 0::2].min(axis=0)).all() and (f[k, 1::2] >= sub[:, 1::2].max(axis=0)).all()
 
 

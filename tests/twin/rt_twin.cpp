@@ -25,8 +25,11 @@ namespace {
 struct TwinScene {
     SceneView V{};
     std::vector<WalkNode> nodes;
+    std::vector<DevRect> rects;
+    std::vector<DevBox> boxes;
     explicit TwinScene(const rt_scene_desc* D) {
-        V.prims = D->prims; V.spheres = D->spheres; V.rects = D->rects; V.boxes = D->boxes; V.xforms = D->xforms;
+        make_device_shapes(D, rects, boxes);
+        V.prims = D->prims; V.spheres = D->spheres; V.rects = rects.data(); V.boxes = boxes.data(); V.xforms = D->xforms;
         V.materials = D->materials; V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
         make_walk_nodes(D, nodes);
         V.bvh = nodes.data();
