@@ -214,9 +214,20 @@ RT_HD double rcp_near(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
+RT_HD double rsqrt_near(double x) {  // 1 / sqrt(x) for positive finite x
+    const double y = __builtin_amdgcn_rsq(x);
+    double r = fma(-x * y, y, 1.0);           // 1 - x y^2
+    double z = fma(y * r, fma(r, 0.375, 0.5), y);
+    r = fma(-x * z, z, 1.0);
+    return fma(z * r, 0.5, z);
+}
+// sine and cosine of 2 pi u, 0 < u < 1 (the argument is reduced exactly in turns, with no large-argument path)
+RT_HD void sincos_turns(float u, float& s, float& c) { sincospif(2.0f * u, &s, &c); }
 #else
 RT_HD double sqrt_near(double x) { return sqrt(x); }
 RT_HD double rcp_near(double x) { return 1.0 / x; }
+RT_HD double rsqrt_near(double x) { return 1.0 / sqrt(x); }
+RT_HD void sincos_turns(float u, float& s, float& c) { const float phi = (2.0f * RT_PI_F) * u; s = sinf(phi); c = cosf(phi); }
 #endif
 // Near root (-half_b - sqrt(disc)) / a of shape.rs:262-270; false when the discriminant is negative.
 RT_HD bool sphere_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time, double& t_out) {
@@ -386,7 +397,7 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
         const D3 c = sphere_center(sp, moving, time);
         const D3 p = ray_at(o, d, t64);
         const D3 pc = p - c;
-        const double inv_len = 1.0 / sqrt(dot(pc, pc));
+        const double inv_len = rsqrt_near(dot(pc, pc));
         nx = pc.x * inv_len; ny = pc.y * inv_len; nz = pc.z * inv_len;
         if (want_uv) {
             const D3 q = pc * (1.0 / sp.radius);  // shape.rs:275 divides by the signed radius
@@ -409,7 +420,7 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
             flip_side = (side & 1) == 0;  // the x0 / y0 / z0 sides are Flipped (outward normals)
         }
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
-        const double t64 = (hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321
+        const double t64 = (hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321 (a true division: a ray parallel to the plane must give +-inf or NaN as there)
         const D3 p = ray_at(o, d, t64);
         if (want_uv) {
             uu = (compd(p, p1) - x0) / (x1 - x0);
@@ -784,11 +795,12 @@ RT_HD V3 texture_color(const SceneView& S, uint32_t tex, float u, float v, V3 p)
 // f64 (on fp32 cos/sin) so that the z component keeps its distance from +-1, which Lambertian
 // scattering off a z-facing surface depends on.
 RT_HD D3 random_unit_vector_d(float u_phi, float u_z) {
-    float phi = (2.0f * RT_PI_F) * u_phi;
+    float sn, cs;
+    sincos_turns(u_phi, sn, cs);
     double z = 2.0 * (double)u_z - 1.0;
     double r = 1.0 - z * z;
-    double x = r * (double)cosf(phi), y = r * (double)sinf(phi);
-    double inv = 1.0 / sqrt(x * x + y * y + z * z);
+    double x = r * (double)cs, y = r * (double)sn;
+    double inv = rsqrt_near(x * x + y * y + z * z);  // >= 3/4 of 1: never zero
     return d3(x * inv, y * inv, z * inv);
 }
 RT_HD V3 random_unit_vector(float u_phi, float u_z) { return v3(random_unit_vector_d(u_phi, u_z)); }
