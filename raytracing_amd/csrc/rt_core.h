@@ -221,12 +221,16 @@ RT_HD double rsqrt_near(double x) {  // 1 / sqrt(x) for positive finite x
     r = fma(-x * z, z, 1.0);
     return fma(z * r, 0.5, z);
 }
+// 1 / direction for the walk (the hardware reciprocal, within an ulp; the walk's node boxes are widened by far more, and the
+// exact leaf tests of one ray all use the same value)
+RT_HD V3 ray_inv(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 // sine and cosine of 2 pi u, 0 < u < 1 (the argument is reduced exactly in turns, with no large-argument path)
 RT_HD void sincos_turns(float u, float& s, float& c) { sincospif(2.0f * u, &s, &c); }
 #else
 RT_HD double sqrt_near(double x) { return sqrt(x); }
 RT_HD double rcp_near(double x) { return 1.0 / x; }
 RT_HD double rsqrt_near(double x) { return 1.0 / sqrt(x); }
+RT_HD V3 ray_inv(V3 d) { return v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 RT_HD void sincos_turns(float u, float& s, float& c) { const float phi = (2.0f * RT_PI_F) * u; s = sinf(phi); c = cosf(phi); }
 #endif
 // Near root (-half_b - sqrt(disc)) / a of shape.rs:262-270; false when the discriminant is negative.
@@ -715,7 +719,7 @@ RT_HD void walk_leaf_generic(const SceneView& S, const Ray& r, float tmin, const
 // stands on a leaf, the outer loop runs the (much longer) primitive test, so the lanes of a wave run their
 // primitive tests together, once per round.
 RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax, const DrawKey& key, float& best_t, uint32_t& best_prim, int& best_side) {
-    const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const V3 inv = ray_inv(r.d);
     const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
     Walk w; walk_init(w, tmax);
     const uint32_t n = S.n_bvh_nodes;

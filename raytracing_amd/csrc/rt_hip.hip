@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
                 r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
                 path = __float_as_uint(b.w);
                 pixel = __float_as_uint(q.thr[mine].w);
-                inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                inv = ray_inv(r.d);
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
                 walk_init(w, RT_INF_F);
                 slot = mine; p0 = RT_BVH_NONE; p1 = RT_BVH_NONE;
