@@ -5,8 +5,8 @@
 One step = one full frame of the workload BASELINE.json quotes its metric on: the reference's
 final_scene example at 800x800, 10 000 samples per pixel, 50 reflections, tile-split over the N
 ranks and gathered on rank 0 (one RCCL sum-reduce of the f64 frame).  The scene is resident on
-the device before the timed region; warm-up steps render the same frame at 64 spp (they size the
-workspace and fix the point where the tail kernel takes over).
+the device before the timed region; warm-up steps render the same frame at 128 spp (they size the
+workspace).
 
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (BVH traversal) against the
 fp32 vector peak: algorithmic flops per path segment are counted by the CPU oracle on the
@@ -113,7 +113,7 @@ def main():
     cam = rt.Camera(co)
     scene.device(local_rank)
     io = rt.ImageOptions(HEIGHT, WIDTH, args.spp, DEPTH)
-    io_warm = rt.ImageOptions(HEIGHT, WIDTH, min(64, args.spp), DEPTH)
+    io_warm = rt.ImageOptions(HEIGHT, WIDTH, min(128, args.spp), DEPTH)
 
     def sync():
         torch.cuda.synchronize()
