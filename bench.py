@@ -140,7 +140,9 @@ def main():
         samples = WIDTH * HEIGHT * args.spp * args.steps
         value = samples / elapsed / 1e6
         # dominant-kernel timing: a profiled render (HIP events around every launch, on the launch stream) of this rank's share
-        prof_io = rt.ImageOptions(HEIGHT, WIDTH, min(128, args.spp), DEPTH)
+        # (104 spp = one whole pass of 64 M paths at 800x800 on one GPU: every launch of the profile is a full-size one, and a kernel
+        # trace of `bench.py --spp 104 --one-stream` averages over launches of exactly this kind)
+        prof_io = rt.ImageOptions(HEIGHT, WIDTH, min(104, args.spp), DEPTH)
         dmean = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.float64, device="cuda")
         scene.render_device(cam, prof_io, rt.RenderOptions(seed=1, rank=0, world_size=world, tile_w=16, tile_h=16, flags=_abi.RT_RENDER_PROFILE,
                                                            stream=torch.cuda.current_stream().cuda_stream), dmean.data_ptr())
