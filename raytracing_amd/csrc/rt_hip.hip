@@ -355,12 +355,16 @@ static rt_status fail(rt_status s, const std::string& m) { g_err = m; return s; 
         }                                                                                                      \
     } while (0)
 
+#ifndef RT_PASS_PARTS
+#define RT_PASS_PARTS 2   // parts a pass is split into when splitting pays (each on a stream of its own)
+#endif
+#define RT_MAX_PARTS 4
 struct rt_scene {
     int device = 0;
     SceneView view{};
     std::vector<void*> allocs;
-    hipStream_t own_stream = nullptr, side_stream = nullptr;  // side_stream: second half of a pass (see render_impl)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t own_stream = nullptr, side_stream[RT_MAX_PARTS - 1] = {};  // side streams: the other parts of a pass (see render_impl)
+    hipEvent_t ev_fork = nullptr, ev_join[RT_MAX_PARTS - 1] = {};
     bool lds_attr_set = false;
     // workspace
     uint64_t ws_paths = 0, ws_pixels = 0;
@@ -492,9 +496,9 @@ void rt_scene_destroy(rt_scene* sc) {
     for (void* p : sc->allocs) (void)hipFree(p);
     for (auto& e : sc->event_pool) (void)hipEventDestroy(e);
     if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
-    if (sc->side_stream) (void)hipStreamDestroy(sc->side_stream);
+    for (auto& x : sc->side_stream) if (x) (void)hipStreamDestroy(x);
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
-    if (sc->ev_join) (void)hipEventDestroy(sc->ev_join);
+    for (auto& x : sc->ev_join) if (x) (void)hipEventDestroy(x);
     delete sc;
 }
 
@@ -555,9 +559,9 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     V.n_prims = D->n_prims;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sc->side_stream, hipStreamNonBlocking);
+    for (auto& x : sc->side_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming);
+    for (auto& x : sc->ev_join) if (e == hipSuccess) e = hipEventCreateWithFlags(&x, hipEventDisableTiming);
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("stream / event creation: ") + hipGetErrorString(e)); }
     *out = sc;
     return RT_OK;
@@ -584,7 +588,7 @@ static rt_status ensure_workspace(rt_scene* sc, uint64_t n_paths, uint64_t n_pix
     if ((st = alloc((void**)&sc->values, n_paths * sizeof(float4))) != RT_OK) return st;
     if ((st = alloc((void**)&sc->accum, n_pixels * 3 * sizeof(double))) != RT_OK) return st;
     if ((st = alloc((void**)&sc->owned, n_pixels * sizeof(uint32_t))) != RT_OK) return st;
-    if ((st = alloc((void**)&sc->counts, 2 * (size_t)n_counts * sizeof(uint32_t))) != RT_OK) return st;  // one set per half pass
+    if ((st = alloc((void**)&sc->counts, RT_MAX_PARTS * (size_t)n_counts * sizeof(uint32_t))) != RT_OK) return st;  // one set per part of a pass
     HIP_TRY(hipHostMalloc((void**)&sc->h_counts, n_counts * sizeof(uint32_t), hipHostMallocDefault));
     sc->ws_paths = n_paths; sc->ws_pixels = n_pixels; sc->n_counts = n_counts;
     return RT_OK;
@@ -736,24 +740,24 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         const bool readback = tail_from < 0 || profile || force_wavefront;
         const bool calibrating = tail_from < 0 && !profile;  // this pass also times its kernels, to see whether splitting later passes pays
         L.profile = profile || calibrating;
-        const int n_halves = (!readback && split_pays && ns >= 2 && !(ro->flags & RT_RENDER_ONE_STREAM)) ? 2 : 1;
-        Half half[2];
+        const int n_halves = (!readback && split_pays && ns >= RT_PASS_PARTS && !(ro->flags & RT_RENDER_ONE_STREAM)) ? RT_PASS_PARTS : 1;
+        Half half[RT_MAX_PARTS];
         uint32_t sample_off = 0;
         for (int k = 0; k < n_halves; ++k) {
             Half& h = half[k];
-            const uint32_t ns_k = n_halves == 1 ? ns : (k == 0 ? (ns + 1) / 2 : ns / 2);
+            const uint32_t ns_k = ns / n_halves + ((uint32_t)k < ns % n_halves ? 1u : 0u);
             const size_t path_off = (size_t)sample_off * n_owned;
-            h.stream = k == 0 ? stream : sc->side_stream;
+            h.stream = k == 0 ? stream : sc->side_stream[k - 1];
             h.P = P; h.P.sample_base = (uint32_t)s0 + sample_off; h.P.n_paths = ns_k * n_owned;
             for (int j = 0; j < 2; ++j) { h.q[j].od0 = sc->q[j].od0 + path_off; h.q[j].od1 = sc->q[j].od1 + path_off; h.q[j].thr = sc->q[j].thr + path_off; }
             h.hits = sc->hits + path_off; h.counts = sc->counts + (size_t)k * n_counts; h.values = sc->values + path_off; h.cur = 0;
             sample_off += ns_k;
         }
-        if (n_halves == 2) {  // the second stream starts after everything queued so far (the previous pass's resolve reads `values`)
+        if (n_halves > 1) {  // the other streams start after everything queued so far (the previous pass's resolve reads `values`)
             HIP_TRY(hipEventRecord(sc->ev_fork, stream));
-            HIP_TRY(hipStreamWaitEvent(sc->side_stream, sc->ev_fork, 0));
+            for (int k = 1; k < n_halves; ++k) HIP_TRY(hipStreamWaitEvent(sc->side_stream[k - 1], sc->ev_fork, 0));
         }
-        uint32_t grid[2], shade_grid[2], trav_grid[2];
+        uint32_t grid[RT_MAX_PARTS], shade_grid[RT_MAX_PARTS], trav_grid[RT_MAX_PARTS];
         for (int k = 0; k < n_halves; ++k) {
             Half& h = half[k];
             const uint32_t grid_full = (h.P.n_paths + RT_BS - 1) / RT_BS;
@@ -804,9 +808,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 sc->prof.segments += sc->h_counts[0];
             }
         }
-        if (n_halves == 2) {  // both halves' values are complete before the per-pixel sums
-            HIP_TRY(hipEventRecord(sc->ev_join, sc->side_stream));
-            HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join, 0));
+        for (int k = 1; k < n_halves; ++k) {  // every part's values are complete before the per-pixel sums
+            HIP_TRY(hipEventRecord(sc->ev_join[k - 1], sc->side_stream[k - 1]));
+            HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join[k - 1], 0));
         }
         if ((st = L.begin(RT_K_RESOLVE, &ev)) != RT_OK) return st;
         hipLaunchKernelGGL(k_resolve, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, sc->values, sc->accum, n_owned, ns);
