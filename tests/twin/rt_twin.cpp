@@ -27,13 +27,14 @@ struct TwinScene {
     std::vector<WalkNode> nodes;
     std::vector<DevRect> rects;
     std::vector<DevBox> boxes;
-    explicit TwinScene(const rt_scene_desc* D) {
+    // with_nodes = false: for callers that never walk the tree (the node array takes some milliseconds to make)
+    explicit TwinScene(const rt_scene_desc* D, bool with_nodes = true) {
         make_device_shapes(D, rects, boxes);
         V.prims = D->prims; V.spheres = D->spheres; V.rects = rects.data(); V.boxes = boxes.data(); V.xforms = D->xforms;
         V.materials = D->materials; V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
-        make_walk_nodes(D, nodes);
+        if (with_nodes) make_walk_nodes(D, nodes);
         V.bvh = nodes.data();
-        V.n_prims = D->n_prims; V.n_bvh_nodes = (uint32_t)nodes.size() - 1;
+        V.n_prims = D->n_prims; V.n_bvh_nodes = with_nodes ? (uint32_t)nodes.size() - 1 : 0;
         for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     }
     TwinScene(const TwinScene&) = delete;
@@ -44,7 +45,7 @@ extern "C" {
 
 void twin_intersect_batch(const rt_scene_desc* D, int64_t scope, const rt_ray* rays, uint64_t n, float tmin, float tmax, uint64_t seed,
                           const float* medium_u, rt_hit* out) {
-    const TwinScene scene(D); const SceneView& S = scene.V;
+    const TwinScene scene(D, scope < 0); const SceneView& S = scene.V;
     for (uint64_t i = 0; i < n; ++i) {
         Ray r; r.o = v3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
         r.d = v3(rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]); r.time = rays[i].time;
@@ -77,7 +78,7 @@ void twin_camera_rays(const rt_camera* cam, uint32_t width, uint32_t height, uin
 // One shading event on a given hit record: returns scattered flag, colour, new ray.
 void twin_material_scatter(const rt_scene_desc* D, const rt_hit* h, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, int32_t* scattered,
                            float* color, float* ray_o, float* ray_d) {
-    const TwinScene scene(D); const SceneView& S = scene.V;
+    const TwinScene scene(D, false); const SceneView& S = scene.V;
     Hit hh; hh.t = h->t; hh.u = h->u; hh.v = h->v; hh.prim = h->prim;
     hh.point = v3(h->point[0], h->point[1], h->point[2]); hh.normal = v3(h->normal[0], h->normal[1], h->normal[2]);
     hh.in_vec = v3(h->in_vec[0], h->in_vec[1], h->in_vec[2]);
