@@ -118,10 +118,10 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #endif
 #define RT_TRAV_GROUP 256u    // rays dealt to a workgroup at a time
 #ifndef RT_STUCK_MAX
-#define RT_STUCK_MAX 16       // ... or once this many lanes cannot step (two leaves pending, or out of the tree with one)
+#define RT_STUCK_MAX 12       // ... or once this many lanes cannot step (two leaves pending, or out of the tree with one)
 #endif
 #ifndef RT_STEPS_PER_TURN
-#define RT_STEPS_PER_TURN 8   // node steps between two looks at the wave's state
+#define RT_STEPS_PER_TURN 10  // node steps between two looks at the wave's state
 #endif
 template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LDS ? 6 : 1) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
