@@ -415,19 +415,32 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
         }
         px = p.x; py = p.y; pz = p.z;
     } else {
-        uint32_t axis; double x0, y0, x1, y1, hgt, unused; bool flip_side = false;
+        // the plane first; the extents are only looked at for (u, v)
+        uint32_t axis; double hgt; bool flip_side = false;
         if (P.geom == RT_GEOM_RECT) {
-            const DevRect R = S.rects[P.geom_index];
-            axis = R.axis; x0 = coord<double>(R.x0, R.x0_lo); y0 = coord<double>(R.y0, R.y0_lo); x1 = coord<double>(R.x1, R.x1_lo); y1 = coord<double>(R.y1, R.y1_lo);
-            hgt = coord<double>(R.h, R.h_lo);
+            const DevRect& R = S.rects[P.geom_index];
+            axis = R.axis; hgt = coord<double>(R.h, R.h_lo);
         } else {
-            box_side<double>(S.boxes[P.geom_index], side, axis, x0, y0, x1, y1, hgt, unused);
-            flip_side = (side & 1) == 0;  // the x0 / y0 / z0 sides are Flipped (outward normals)
+            const DevBox& B = S.boxes[P.geom_index];
+            axis = (uint32_t)(side >> 1);
+            const bool upper = (side & 1) != 0;
+            const float hh = axis == 0 ? (upper ? B.max[0] : B.min[0]) : (axis == 1 ? (upper ? B.max[1] : B.min[1]) : (upper ? B.max[2] : B.min[2]));
+            const float hl = axis == 0 ? (upper ? B.max_lo[0] : B.min_lo[0]) : (axis == 1 ? (upper ? B.max_lo[1] : B.min_lo[1]) : (upper ? B.max_lo[2] : B.min_lo[2]));
+            hgt = coord<double>(hh, hl);
+            flip_side = !upper;  // the x0 / y0 / z0 sides are Flipped (outward normals)
         }
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
         const double t64 = (hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321 (a true division: a ray parallel to the plane must give +-inf or NaN as there)
         const D3 p = ray_at(o, d, t64);
         if (want_uv) {
+            double x0, y0, x1, y1, h_, unused;
+            if (P.geom == RT_GEOM_RECT) {
+                const DevRect& R = S.rects[P.geom_index];
+                x0 = coord<double>(R.x0, R.x0_lo); y0 = coord<double>(R.y0, R.y0_lo); x1 = coord<double>(R.x1, R.x1_lo); y1 = coord<double>(R.y1, R.y1_lo);
+            } else {
+                uint32_t axis_;
+                box_side<double>(S.boxes[P.geom_index], side, axis_, x0, y0, x1, y1, h_, unused);
+            }
             uu = (compd(p, p1) - x0) / (x1 - x0);
             vv = (compd(p, p2) - y0) / (y1 - y0);
         }
