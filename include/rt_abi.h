@@ -261,6 +261,19 @@ typedef struct rt_hit { /* IntersectionPoint, shape.rs:539-550 */
 rt_status rt_intersect_batch(rt_scene* scene, int64_t scope, const rt_ray* rays, uint64_t n, float tmin, float tmax,
                              uint64_t seed, const float* medium_u, rt_hit* out);
 
+/* Parity hook for `Material::scatter(&self, p, rng) -> RayHit` (src/materials.rs:28-113) together with the
+ * texture look-up `Texture::color_at` (src/textures.rs:46-78): one shading event per hit record, run by the
+ * same device code the renderer shades with. */
+typedef struct rt_scatter { /* RayHit, src/lib.rs:300-306 */
+    int32_t scattered;      /* 1 = RayHit::Scattered { ray, attenuation }, 0 = RayHit::Emitted(colour) */
+    float color[3];         /* the attenuation, or the emitted colour */
+    float origin[3], direction[3]; /* the scattered ray; unspecified when nothing is scattered */
+} rt_scatter;
+/* hits[i].prim names the object whose material scatters (hits[i].hit is ignored).  keys (optional, 3 per
+ * record): the pixel, sample and bounce whose Philox streams supply the draws; NULL = (i, 0, 0).
+ * hits / keys / out are host pointers. */
+rt_status rt_scatter_batch(rt_scene* scene, const rt_hit* hits, uint64_t n, uint64_t seed, const uint32_t* keys, rt_scatter* out);
+
 /* Camera rays exactly as pixel() draws them (src/lib.rs:55-60, :389-401) for n
  * (column i, row-from-bottom j, sample) triples; host pointers. */
 rt_status rt_camera_rays(rt_scene* scene, const rt_camera* camera, const rt_image_options* image_options, uint64_t seed,

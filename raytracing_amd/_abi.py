@@ -90,6 +90,10 @@ class rt_hit(C.Structure):
                 ("in_vec", C.c_float * 3), ("u", C.c_float), ("v", C.c_float)]
 
 
+class rt_scatter(C.Structure):
+    _fields_ = [("scattered", C.c_int32), ("color", C.c_float * 3), ("origin", C.c_float * 3), ("direction", C.c_float * 3)]
+
+
 class rt_profile(C.Structure):
     _fields_ = [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("samples", C.c_uint64), ("segments", C.c_uint64),
                 ("traverse_segments", C.c_uint64), ("passes", C.c_uint64)]
@@ -109,6 +113,7 @@ HIP_SYMBOLS = {
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_image_options), C.POINTER(rt_render_options), C.c_void_p]),
     "rt_quantise_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rt_intersect_batch": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(rt_ray), C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.POINTER(rt_hit)]),
+    "rt_scatter_batch": (C.c_int, [C.c_void_p, C.POINTER(rt_hit), C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(rt_scatter)]),
     "rt_camera_rays": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_image_options), C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(rt_ray)]),
     "rt_get_profile": (C.c_int, [C.c_void_p, C.POINTER(rt_profile)]),

@@ -276,6 +276,8 @@ def rays_to_c(origins, directions, times):
 HIT_DTYPE = np.dtype([("hit", np.int32), ("prim", np.uint32), ("t", np.float32), ("point", np.float32, 3), ("normal", np.float32, 3),
                       ("in_vec", np.float32, 3), ("u", np.float32), ("v", np.float32)])
 assert HIT_DTYPE.itemsize == C.sizeof(_abi.rt_hit)
+SCATTER_DTYPE = np.dtype([("scattered", np.int32), ("color", np.float32, 3), ("origin", np.float32, 3), ("direction", np.float32, 3)])
+assert SCATTER_DTYPE.itemsize == C.sizeof(_abi.rt_scatter)
 
 
 class Scene:
@@ -381,6 +383,17 @@ class Scene:
         mu = None if medium_u is None else np.ascontiguousarray(np.broadcast_to(np.asarray(medium_u, dtype=np.float32), (n,)))
         _abi.check(self._hip.rt_intersect_batch(self.device(), scope, rays.ctypes.data_as(C.POINTER(_abi.rt_ray)), n, tmin, tmax, seed,
                                                 mu.ctypes.data_as(C.c_void_p) if mu is not None else None, out.ctypes.data_as(C.POINTER(_abi.rt_hit))))
+        return out
+
+    def scatter_batch(self, hits, seed=0, keys=None):
+        """rt_scatter_batch: Material::scatter (materials.rs:28) on HIT_DTYPE records; keys = (n, 3) pixel / sample / bounce.
+        Returns a SCATTER_DTYPE array."""
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        n = hits.shape[0]
+        out = np.zeros(n, dtype=SCATTER_DTYPE)
+        k = None if keys is None else np.ascontiguousarray(keys, dtype=np.uint32).reshape(n, 3)
+        _abi.check(self._hip.rt_scatter_batch(self.device(), hits.ctypes.data_as(C.POINTER(_abi.rt_hit)), n, seed,
+                                              k.ctypes.data_as(C.c_void_p) if k is not None else None, out.ctypes.data_as(C.POINTER(_abi.rt_scatter))))
         return out
 
     def camera_rays(self, camera: Camera, image_options: ImageOptions, seed, px_i, px_j, sample):

@@ -331,6 +331,24 @@ __global__ void __launch_bounds__(RT_BS) k_intersect_batch(SceneView S, int64_t 
     out[i] = o;
 }
 
+__global__ void __launch_bounds__(RT_BS) k_scatter_batch(SceneView S, const rt_hit* hits, uint64_t n, uint32_t k0, uint32_t k1, const uint32_t* keys, rt_scatter* out) {
+    uint64_t i = (uint64_t)blockIdx.x * RT_BS + threadIdx.x;
+    if (i >= n) return;
+    const rt_hit in = hits[i];
+    Hit h; h.t = in.t; h.u = in.u; h.v = in.v; h.prim = in.prim;
+    h.point = v3(in.point[0], in.point[1], in.point[2]); h.normal = v3(in.normal[0], in.normal[1], in.normal[2]);
+    h.in_vec = v3(in.in_vec[0], in.in_vec[1], in.in_vec[2]);
+    DrawKey key; key.k0 = k0; key.k1 = k1; key.medium_u = -1.0f;
+    key.pixel = keys ? keys[3 * i] : (uint32_t)i; key.sample = keys ? keys[3 * i + 1] : 0u; key.bounce = keys ? keys[3 * i + 2] : 0u;
+    const Scatter sc = material_scatter(S, h, key);
+    rt_scatter o;
+    o.scattered = sc.scattered ? 1 : 0;
+    o.color[0] = sc.color.x; o.color[1] = sc.color.y; o.color[2] = sc.color.z;
+    o.origin[0] = sc.o.x; o.origin[1] = sc.o.y; o.origin[2] = sc.o.z;
+    o.direction[0] = sc.d.x; o.direction[1] = sc.d.y; o.direction[2] = sc.d.z;
+    out[i] = o;
+}
+
 __global__ void __launch_bounds__(RT_BS) k_camera_rays(rt_camera cam, uint32_t width, uint32_t height, uint32_t k0, uint32_t k1, uint64_t n,
                                                        const uint32_t* px_i, const uint32_t* px_j, const uint32_t* sample, rt_ray* out) {
     uint64_t k = (uint64_t)blockIdx.x * RT_BS + threadIdx.x;
@@ -906,6 +924,28 @@ rt_status rt_intersect_batch(rt_scene* sc, int64_t scope, const rt_ray* rays, ui
     TRY2(hipMemcpy(out, d_out, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
     cleanup();
     return st;
+}
+
+rt_status rt_scatter_batch(rt_scene* sc, const rt_hit* hits, uint64_t n, uint64_t seed, const uint32_t* keys, rt_scatter* out) {
+    if (!sc || (!hits && n) || (!out && n)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return RT_OK;
+    if (n >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "batch too large");
+    for (uint64_t i = 0; i < n; ++i)
+        if (hits[i].prim >= sc->view.n_prims) return fail(RT_ERR_INVALID_ARGUMENT, "hit record names a primitive this scene does not have");
+    HIP_TRY(hipSetDevice(sc->device));
+    rt_hit* d_hits = nullptr; rt_scatter* d_out = nullptr; uint32_t* d_keys = nullptr;
+    auto cleanup = [&]() { if (d_hits) (void)hipFree(d_hits); if (d_out) (void)hipFree(d_out); if (d_keys) (void)hipFree(d_keys); };
+    TRY2(hipMalloc((void**)&d_hits, n * sizeof(rt_hit)));
+    TRY2(hipMalloc((void**)&d_out, n * sizeof(rt_scatter)));
+    TRY2(hipMemcpy(d_hits, hits, n * sizeof(rt_hit), hipMemcpyHostToDevice));
+    if (keys) { TRY2(hipMalloc((void**)&d_keys, 3 * n * sizeof(uint32_t))); TRY2(hipMemcpy(d_keys, keys, 3 * n * sizeof(uint32_t), hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_scatter_batch, dim3((uint32_t)((n + RT_BS - 1) / RT_BS)), dim3(RT_BS), 0, sc->own_stream, sc->view, d_hits, n, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), d_keys, d_out);
+    TRY2(hipGetLastError());
+    TRY2(hipStreamSynchronize(sc->own_stream));
+    TRY2(hipMemcpy(out, d_out, n * sizeof(rt_scatter), hipMemcpyDeviceToHost));
+    cleanup();
+    return RT_OK;
 }
 
 rt_status rt_camera_rays(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, uint64_t seed, uint64_t n, const uint32_t* px_i,
