@@ -685,6 +685,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
 
     HIP_TRY(hipMemsetAsync(d_mean_out, 0, (size_t)3 * W * H * sizeof(double), stream));
     std::memset(&sc->prof, 0, sizeof(sc->prof));
+    for (auto& e : sc->events) { sc->event_pool.push_back(e.second.first); sc->event_pool.push_back(e.second.second); }  // left by a call that failed
+    sc->events.clear();
     if (n_owned == 0) { if (sync_at_end) HIP_TRY(hipStreamSynchronize(stream)); return RT_OK; }
 
     // Samples per pass: large passes amortise what every launch costs (the workgroups' copy of the node array into LDS,
