@@ -52,8 +52,17 @@ struct PassParams {
     uint32_t sample_base;  // first sample index of the pass
     uint32_t k0, k1;       // seed
     uint32_t max_depth;
+    uint32_t n_counts;     // queue lengths come in two arrays of this many entries, one behind the other (see queue_slot)
     const uint32_t* owned; // global pixel id (j * width + i) of every owned pixel
 };
+
+// A queue has two ends.  Rays that leave a sphere are written from slot 0 upwards, all others from slot n_paths - 1
+// downwards, and a queue is read front part first: the rays a wave holds at a time then mostly meet one kind of
+// primitive (a ray that leaves one of a thousand packed spheres tests its neighbours next), and a turn of primitive
+// tests mostly runs one kind of test instead of both.  Entry i of a queue with n_front rays at the front:
+__device__ __forceinline__ uint32_t queue_slot(uint32_t i, uint32_t n_front, uint32_t capacity) {
+    return i < n_front ? i : capacity - 1u - (i - n_front);
+}
 
 // Path p of a pass is sample sample_base + p / n_owned of owned pixel p % n_owned.
 __device__ __forceinline__ uint32_t path_sample(const PassParams& P, uint32_t path) {
@@ -72,8 +81,8 @@ __device__ __forceinline__ DrawKey make_key(const PassParams& P, uint32_t path, 
 __global__ void __launch_bounds__(RT_BS) k_raygen(PassParams P, RayQueue q, uint32_t* counts, uint32_t n_counts) {
     uint32_t p = blockIdx.x * RT_BS + threadIdx.x;
     if (p == 0) {
-        counts[0] = P.n_paths;
-        for (uint32_t i = 1; i < n_counts; ++i) counts[i] = 0;
+        counts[0] = P.n_paths;  // camera rays: all at the front
+        for (uint32_t i = 1; i < 2u * n_counts; ++i) counts[i] = 0;
     }
     if (p >= P.n_paths) return;
     const uint32_t sample = path_sample(P, p);
@@ -129,7 +138,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
     extern __shared__ uint4 lds_nodes[];
     __shared__ uint32_t next_ray;
     const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
-    const uint32_t count = *count_ptr;
+    const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_nodes = S.n_bvh_nodes;
     const float tmin = 0.001f;  // lib.rs:90: (0.001, inf)
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
     w.i = n_nodes;  // a lane without a ray rests on the sentinel slot
     uint32_t slot = 0, path = 0, pixel = 0, p0 = RT_BVH_NONE, p1 = RT_BVH_NONE;  // p0, p1: pending leaves (node indices), oldest first
     if (n_nodes == 0)  // nothing to hit: every ray misses
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) hits[i] = make_uint2(0u, RT_HIT_NONE);
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) hits[queue_slot(i, n_front, P.n_paths)] = make_uint2(0u, RT_HIT_NONE);
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -161,14 +170,15 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             const uint32_t local = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t mine = ((local / RT_TRAV_GROUP) * gridDim.x + blockIdx.x) * RT_TRAV_GROUP + local % RT_TRAV_GROUP;
             if (!active && local < my_rays && mine < count) {
-                const float4 a = q.od0[mine], b = q.od1[mine];
+                const uint32_t at = queue_slot(mine, n_front, P.n_paths);
+                const float4 a = q.od0[at], b = q.od1[at];
                 r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
                 path = __float_as_uint(b.w);
-                pixel = __float_as_uint(q.thr[mine].w);
+                pixel = __float_as_uint(q.thr[at].w);
                 inv = ray_inv(r.d);
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
                 walk_init(w, RT_INF_F);
-                slot = mine; p0 = RT_BVH_NONE; p1 = RT_BVH_NONE;
+                slot = at; p0 = RT_BVH_NONE; p1 = RT_BVH_NONE;
                 active = true;
             }
         }
@@ -206,17 +216,18 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 #define RT_SHADE_BS 512
 __global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
-    __shared__ uint32_t wave_cnt[RT_SHADE_BS / 64];
-    __shared__ uint32_t block_base;
-    const uint32_t count = *count_ptr;
+    __shared__ uint32_t wave_cnt[2][RT_SHADE_BS / 64];
+    __shared__ uint32_t block_base[2];
+    const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t base = blockIdx.x * RT_SHADE_BS; base < count; base += gridDim.x * RT_SHADE_BS) {
         const uint32_t i = base + threadIdx.x;
-        bool alive = false;
+        bool alive = false, to_front = false;
         Ray r; V3 thr; uint32_t path = 0, pixel = 0;
         if (i < count) {
-            float4 a = qin.od0[i], b = qin.od1[i], c = qin.thr[i];
-            uint2 hh = hits[i];
+            const uint32_t at = queue_slot(i, n_front, P.n_paths);
+            float4 a = qin.od0[at], b = qin.od1[at], c = qin.thr[at];
+            uint2 hh = hits[at];
             r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
             path = __float_as_uint(b.w);
             thr = v3(c.x, c.y, c.z);
@@ -226,20 +237,24 @@ __global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParam
             bool hit = hh.y != RT_HIT_NONE;
             alive = shade_step(S, r, thr, key, hit, __uint_as_float(hh.x), hh.y & 0x1FFFFFFFu, (int)(hh.y >> 29), bounce + 1 >= P.max_depth, value);
             if (!alive) values[path] = make_float4(value.x, value.y, value.z, 0.0f);
+            else to_front = S.prims[hh.y & 0x1FFFFFFFu].geom <= RT_GEOM_MOVING_SPHERE;  // an alive path has hit something
         }
-        // compaction: ballot + lane prefix inside the wave, one atomic per block
-        const unsigned long long mask = __ballot(alive);
+        // compaction, per end of the queue: ballot + lane prefix inside the wave, one atomic per block and end
+        const unsigned long long mask_f = __ballot(alive && to_front), mask_b = __ballot(alive && !to_front);
+        const unsigned long long mask = to_front ? mask_f : mask_b;
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(mask);
+        if (lane == 0) { wave_cnt[0][wave] = (uint32_t)__popcll(mask_f); wave_cnt[1][wave] = (uint32_t)__popcll(mask_b); }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 2) {
+            const uint32_t e = threadIdx.x;
             uint32_t total = 0;
-            for (int w = 0; w < RT_SHADE_BS / 64; ++w) { uint32_t c = wave_cnt[w]; wave_cnt[w] = total; total += c; }
-            block_base = total ? atomicAdd(next_count, total) : 0u;
+            for (int w = 0; w < RT_SHADE_BS / 64; ++w) { uint32_t c = wave_cnt[e][w]; wave_cnt[e][w] = total; total += c; }
+            block_base[e] = total ? atomicAdd(next_count + e * P.n_counts, total) : 0u;
         }
         __syncthreads();
         if (alive) {
-            const uint32_t slot = block_base + wave_cnt[wave] + prefix;
+            const uint32_t k = block_base[to_front ? 0 : 1] + wave_cnt[to_front ? 0 : 1][wave] + prefix;
+            const uint32_t slot = to_front ? k : P.n_paths - 1u - k;
             qout.od0[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
             qout.od1[slot] = make_float4(r.d.y, r.d.z, r.time, __uint_as_float(path));
             qout.thr[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
@@ -254,10 +269,11 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_tail(Scen
                                                      uint32_t first_bounce) {
     extern __shared__ uint4 lds_nodes[];
     const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
-    const uint32_t count = *count_ptr;
+    const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     uint32_t segments = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        float4 a = q.od0[i], b = q.od1[i], c = q.thr[i];
+        const uint32_t at = queue_slot(i, n_front, P.n_paths);
+        float4 a = q.od0[at], b = q.od1[at], c = q.thr[at];
         Ray r; r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
         const uint32_t path = __float_as_uint(b.w);
         V3 thr = v3(c.x, c.y, c.z);
@@ -606,8 +622,8 @@ static rt_status ensure_workspace(rt_scene* sc, uint64_t n_paths, uint64_t n_pix
     if ((st = alloc((void**)&sc->values, n_paths * sizeof(float4))) != RT_OK) return st;
     if ((st = alloc((void**)&sc->accum, n_pixels * 3 * sizeof(double))) != RT_OK) return st;
     if ((st = alloc((void**)&sc->owned, n_pixels * sizeof(uint32_t))) != RT_OK) return st;
-    if ((st = alloc((void**)&sc->counts, RT_MAX_PARTS * (size_t)n_counts * sizeof(uint32_t))) != RT_OK) return st;  // one set per part of a pass
-    HIP_TRY(hipHostMalloc((void**)&sc->h_counts, n_counts * sizeof(uint32_t), hipHostMallocDefault));
+    if ((st = alloc((void**)&sc->counts, RT_MAX_PARTS * 2 * (size_t)n_counts * sizeof(uint32_t))) != RT_OK) return st;  // per part of a pass: front and back lengths
+    HIP_TRY(hipHostMalloc((void**)&sc->h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
     sc->ws_paths = n_paths; sc->ws_pixels = n_pixels; sc->n_counts = n_counts;
     return RT_OK;
 }
@@ -727,6 +743,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     P.cam = *cam; P.width = W; P.height = H; P.n_owned = n_owned;
     P.owned_magic = n_owned > 1 ? ~0ull / n_owned + 1 : 0;
     P.k0 = (uint32_t)ro->seed; P.k1 = (uint32_t)(ro->seed >> 32); P.max_depth = depth; P.owned = sc->owned;
+    P.n_counts = depth + 2;
 
     const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;
     int tail_from = force_tail ? 0 : -1;  // bounce at which k_tail takes over; -1 = not calibrated yet
@@ -770,7 +787,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             h.stream = k == 0 ? stream : sc->side_stream[k - 1];
             h.P = P; h.P.sample_base = (uint32_t)s0 + sample_off; h.P.n_paths = ns_k * n_owned;
             for (int j = 0; j < 2; ++j) { h.q[j].od0 = sc->q[j].od0 + path_off; h.q[j].od1 = sc->q[j].od1 + path_off; h.q[j].thr = sc->q[j].thr + path_off; }
-            h.hits = sc->hits + path_off; h.counts = sc->counts + (size_t)k * n_counts; h.values = sc->values + path_off; h.cur = 0;
+            h.hits = sc->hits + path_off; h.counts = sc->counts + (size_t)k * 2 * n_counts; h.values = sc->values + path_off; h.cur = 0;
             sample_off += ns_k;
         }
         if (n_halves > 1) {  // the other streams start after everything queued so far (the previous pass's resolve reads `values`)
@@ -808,10 +825,12 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             HIP_TRY(hipGetLastError());
             if (readback) {
                 HIP_TRY(hipMemcpyAsync(sc->h_counts, half[0].counts + b, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(sc->h_counts + 2, half[0].counts + n_counts + b, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
-                sc->prof.segments += sc->h_counts[0]; sc->prof.traverse_segments += sc->h_counts[0];
-                if (sc->h_counts[1] == 0) { finished = true; break; }
-                if (tail_from < 0 && !force_wavefront && sc->h_counts[1] <= tail_threshold) tail_from = (int)b + 1;
+                const uint32_t now = sc->h_counts[0] + sc->h_counts[2], next = sc->h_counts[1] + sc->h_counts[3];
+                sc->prof.segments += now; sc->prof.traverse_segments += now;
+                if (next == 0) { finished = true; break; }
+                if (tail_from < 0 && !force_wavefront && next <= tail_threshold) tail_from = (int)b + 1;
             }
         }
         if (tail_from < 0 && !force_wavefront) tail_from = (int)depth;
