@@ -52,14 +52,17 @@ struct PassParams {
     uint32_t sample_base;  // first sample index of the pass
     uint32_t k0, k1;       // seed
     uint32_t max_depth;
+    uint32_t up_axis; float up_sign;  // the axis the camera's up vector (cam.v) is closest to, and its sign there
     uint32_t n_counts;     // queue lengths come in two arrays of this many entries, one behind the other (see queue_slot)
     const uint32_t* owned; // global pixel id (j * width + i) of every owned pixel
 };
 
-// A queue has two ends.  Rays that leave a sphere are written from slot 0 upwards, all others from slot n_paths - 1
-// downwards, and a queue is read front part first: the rays a wave holds at a time then mostly meet one kind of
-// primitive (a ray that leaves one of a thousand packed spheres tests its neighbours next), and a turn of primitive
-// tests mostly runs one kind of test instead of both.  Entry i of a queue with n_front rays at the front:
+// A queue has two ends.  Scattered rays that point up (along the axis the camera's up vector is closest to) are written
+// from slot 0 upwards, the others from slot n_paths - 1 downwards, and a queue is read front part first: the rays a
+// wave or a workgroup holds at a time then go to the same half of the scene, meet more of the same primitives and
+// materials, and both the primitive tests of the walk and the shading diverge less (final_scene: shading 8 % faster,
+// the walk 3 %; the kind of primitive a ray leaves is as good a key for the walk and half as good for shading).
+// Entry i of a queue with n_front rays at the front:
 __device__ __forceinline__ uint32_t queue_slot(uint32_t i, uint32_t n_front, uint32_t capacity) {
     return i < n_front ? i : capacity - 1u - (i - n_front);
 }
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParam
             bool hit = hh.y != RT_HIT_NONE;
             alive = shade_step(S, r, thr, key, hit, __uint_as_float(hh.x), hh.y & 0x1FFFFFFFu, (int)(hh.y >> 29), bounce + 1 >= P.max_depth, value);
             if (!alive) values[path] = make_float4(value.x, value.y, value.z, 0.0f);
-            else to_front = S.prims[hh.y & 0x1FFFFFFFu].geom <= RT_GEOM_MOVING_SPHERE;  // an alive path has hit something
+            else to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
         }
         // compaction, per end of the queue: ballot + lane prefix inside the wave, one atomic per block and end
         const unsigned long long mask_f = __ballot(alive && to_front), mask_b = __ballot(alive && !to_front);
@@ -744,6 +747,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     P.owned_magic = n_owned > 1 ? ~0ull / n_owned + 1 : 0;
     P.k0 = (uint32_t)ro->seed; P.k1 = (uint32_t)(ro->seed >> 32); P.max_depth = depth; P.owned = sc->owned;
     P.n_counts = depth + 2;
+    P.up_axis = 1;
+    for (uint32_t c = 0; c < 3; ++c) if (std::fabs(cam->v[c]) > std::fabs(cam->v[P.up_axis])) P.up_axis = c;
+    P.up_sign = cam->v[P.up_axis] < 0.0 ? -1.0f : 1.0f;
 
     const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;
     int tail_from = force_tail ? 0 : -1;  // bounce at which k_tail takes over; -1 = not calibrated yet
