@@ -157,9 +157,12 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
     bool active = false, exhausted = n_nodes == 0;
     Ray r; r.o = v3(0, 0, 0); r.d = v3(1, 1, 1); r.time = 0.0f;
     V3 inv = v3(1, 1, 1), oi = v3(0, 0, 0);
-    Walk w; walk_init(w, RT_INF_F);
-    w.i = n_nodes;  // a lane without a ray rests on the sentinel slot
-    uint32_t slot = 0, path = 0, pixel = 0, p0 = RT_BVH_NONE, p1 = RT_BVH_NONE;  // p0, p1: pending leaves (node indices), oldest first
+    // The walk's state between turns: the next node, the upper end of the ray interval (the accepted hit's t once there
+    // is one) and the accepted primitive with the box side in the top bits, RT_HIT_NONE while nothing is accepted.
+    uint32_t node = n_nodes;  // a lane without a ray rests on the sentinel slot
+    float t_end = RT_INF_F;
+    uint32_t best = RT_HIT_NONE;
+    uint32_t slot = 0, p0 = RT_BVH_NONE, p1 = RT_BVH_NONE;  // p0, p1: pending leaves (node indices), oldest first
     if (n_nodes == 0)  // nothing to hit: every ray misses
         for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) hits[queue_slot(i, n_front, P.n_paths)] = make_uint2(0u, RT_HIT_NONE);
     for (;;) {
@@ -174,13 +177,12 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             const uint32_t mine = ((local / RT_TRAV_GROUP) * gridDim.x + blockIdx.x) * RT_TRAV_GROUP + local % RT_TRAV_GROUP;
             if (!active && local < my_rays && mine < count) {
                 const uint32_t at = queue_slot(mine, n_front, P.n_paths);
-                const float4 a = q.od0[at], b = q.od1[at];
-                r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
-                path = __float_as_uint(b.w);
-                pixel = __float_as_uint(q.thr[at].w);
+                const float4 a = q.od0[at];
+                const float2 b = *reinterpret_cast<const float2*>(&q.od1[at]);
+                r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y);
                 inv = ray_inv(r.d);
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
-                walk_init(w, RT_INF_F);
+                node = 0; t_end = RT_INF_F; best = RT_HIT_NONE;
                 slot = at; p0 = RT_BVH_NONE; p1 = RT_BVH_NONE;
                 active = true;
             }
@@ -191,21 +193,29 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             continue;
         }
         const unsigned long long pending = __ballot(active && p0 != RT_BVH_NONE);
-        const unsigned long long runnable = __ballot(active && p1 == RT_BVH_NONE && w.i < n_nodes);
+        const unsigned long long runnable = __ballot(active && p1 == RT_BVH_NONE && node < n_nodes);
         const unsigned long long stuck = act & ~runnable & pending;  // two leaves pending, or out of the tree with one
         if (runnable != 0ull && (uint32_t)__popcll(pending) < RT_LEAF_BATCH && (uint32_t)__popcll(stuck) < RT_STUCK_MAX) {
+            Walk w; w.i = node; w.tmax = t_end;
 #pragma unroll
             for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, p0, p1);
+            node = w.i;
         } else {
             if (active && p0 != RT_BVH_NONE) {
+                Walk w; walk_init(w, t_end);
                 w.leaf_node = p0;
                 const uint32_t leaf = S.bvh[p0].prim;
-                if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, make_key(P, path, pixel, bounce), leaf, w);
+                if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) {  // only these leaves need the ray's time (moving spheres) and the path and pixel numbers (they key a medium's draw)
+                    const float4 b = q.od1[slot];
+                    r.time = b.z;
+                    walk_leaf_generic(S, r, tmin, make_key(P, __float_as_uint(b.w), __float_as_uint(q.thr[slot].w), bounce), leaf, w);
+                }
+                if (w.found) { t_end = w.t; best = w.prim | ((uint32_t)w.side << 29); }
                 p0 = p1; p1 = RT_BVH_NONE;
             }
         }
-        if (active && p0 == RT_BVH_NONE && w.i >= n_nodes) {
-            hits[slot] = make_uint2(__float_as_uint(w.t), w.found ? (w.prim | ((uint32_t)w.side << 29)) : RT_HIT_NONE);
+        if (active && p0 == RT_BVH_NONE && node >= n_nodes) {
+            hits[slot] = make_uint2(best != RT_HIT_NONE ? __float_as_uint(t_end) : 0u, best);
             active = false;
         }
     }
