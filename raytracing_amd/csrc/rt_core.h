@@ -815,7 +815,7 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, 
 // Everything else: the general Intersection::intersect.  (An exact leaf arrives here only after walk_leaf_fast
 // has let the ray into its box.)
 RT_HD void walk_leaf_generic(const SceneView& S, const Ray& r, float tmin, const DrawKey& key, uint32_t leaf, Walk& w) {
-    RT_COUNT(leaves); RT_COUNT(prim_tests);
+    RT_COUNT(leaves); RT_COUNT(prim_tests); RT_COUNT(generic_leaves);
     float t; int side;
     if (prim_t(S, leaf & RT_NODE_PRIM_MASK, r.o, r.d, tmin, w.tmax, r.time, key, t, side)) walk_accept(w, t, leaf & RT_NODE_PRIM_MASK, side);
 }

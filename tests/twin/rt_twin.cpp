@@ -15,6 +15,8 @@ static thread_local TwinCounters g_tc;
 static inline void twin_count_nodes() { g_tc.nodes++; }
 static inline void twin_count_leaves() { g_tc.leaves++; if (g_tc.trace && g_tc.trace_n < g_tc.trace_cap) g_tc.trace[g_tc.trace_n++] = (uint32_t)g_tc.nodes; }
 static inline void twin_count_prim_tests() { g_tc.prim_tests++; }
+static unsigned long long g_generic_leaves = 0;  // leaves that took the general primitive test (single-threaded statistics runs only)
+static inline void twin_count_generic_leaves() { g_generic_leaves++; }
 #define RT_COUNT(name) twin_count_##name()
 #include "../../raytracing_amd/csrc/rt_core.h"
 
@@ -88,6 +90,8 @@ void twin_material_scatter(const rt_scene_desc* D, const rt_hit* h, uint64_t see
     color[0] = sc.color.x; color[1] = sc.color.y; color[2] = sc.color.z;
     ray_o[0] = sc.o.x; ray_o[1] = sc.o.y; ray_o[2] = sc.o.z; ray_d[0] = sc.d.x; ray_d[1] = sc.d.y; ray_d[2] = sc.d.z;
 }
+
+unsigned long long twin_generic_leaves(void) { return g_generic_leaves; }
 
 // Per-ray traversal work (nodes visited, leaves reached, primitive tests run) for analysis.
 // trace (optional, n x trace_cap): the node-visit count at which each leaf was reached.

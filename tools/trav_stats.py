@@ -31,6 +31,8 @@ for o, d, t in path_rays(osc, oco, 64, 64, 5, 3000, 12, np.random.default_rng(3)
         o2 = np.zeros(len(rays), dtype=np.uint32)
         lib.twin_traverse_deferred(desc, rays.ctypes.data, len(rays), k, o2.ctypes.data)
         dtot[k] += int(o2.sum())
+lib.twin_generic_leaves.restype = C.c_ulonglong
+print('general primitive tests per segment (stats + ordered + deferred runs together count each ray %d times): %.3f' % (2 + len(dtot), lib.twin_generic_leaves() / n / (2 + len(dtot))))
 print(name, 'segments', n, 'nodes/seg %.2f leaves/seg %.2f prim tests/seg %.2f' % tuple(tot / n))
 lib.twin_traverse_ordered.argtypes = [C.POINTER(_abi.rt_scene_desc), C.c_void_p, C.c_uint64, C.c_void_p]
 print('node tests/seg with k leaves pending:', {k: round(v / n, 2) for k, v in dtot.items()})
