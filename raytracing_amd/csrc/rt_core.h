@@ -501,8 +501,11 @@ struct Ray {
 //                         Behind Translated / Rotated wrappers the centre is the wrapped sphere's centre carried out
 //                         through the wrappers: the near root along the ray in the outer frame is the near root along
 //                         the transformed ray in the sphere's frame (rotations keep lengths), to a few f64 ulps.
-// The slot after the last node is a sentinel (skip link to itself) that a finished or idle walk may read.
-#define RT_NODE_PRIM_MASK 0x1FFFFFFFu
+// A leaf's word also has RT_NODE_LEAF set; the word of an inner node is the index of its first child (the next slot),
+// below RT_NODE_LEAF, so that a step picks its successor from the node's two words without arithmetic.
+// The slot after the last node is a sentinel (both links to itself) that a finished or idle walk may read and step on.
+#define RT_NODE_PRIM_MASK 0x0FFFFFFFu
+#define RT_NODE_LEAF 0x10000000u
 #define RT_NODE_PLAIN_BOX 0x40000000u
 #define RT_NODE_PLAIN_SPHERE 0x20000000u
 
@@ -681,11 +684,12 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
     uint32_t at = 0;
     for (uint32_t i = 0; i < n_in; ++i) { new_index[i] = at; at += 1u + payload_slots(tree[i]); }
     new_index[n_in] = at;
-    nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at, RT_BVH_NONE});
+    nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at, at});
     for (uint32_t i = 0; i < n_in; ++i) {
         const rt_bvh_node& N = tree[i];
-        WalkNode W{N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2], new_index[N.skip], N.prim};
+        WalkNode W{N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2], new_index[N.skip], new_index[i] + 1u};
         if (N.prim != RT_BVH_NONE) {
+            W.prim = RT_NODE_LEAF | (N.prim & RT_BVH_EXACT) | (N.prim & RT_NODE_PRIM_MASK);
             const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
             if (plain_sphere(N)) {
                 W.prim |= RT_NODE_PLAIN_SPHERE;
@@ -752,7 +756,8 @@ RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w)
     RT_COUNT(nodes);
     if (!node_hit(N, inv, oi, tmin, w.tmax)) { w.i = N.skip; return RT_BVH_NONE; }
     w.leaf_node = w.i;
-    w.i = (N.prim != RT_BVH_NONE) ? N.skip : w.i + 1;  // a leaf's skip link also jumps over its payload slot, if any
+    if (N.prim < RT_NODE_LEAF) { w.i = N.prim; return RT_BVH_NONE; }  // inner: on to its first child
+    w.i = N.skip;  // a leaf's skip link also jumps over its payload slot, if any
     return N.prim;
 }
 // The same step without control flow, for lanes in lockstep, with up to two leaves left pending: a leaf the walk meets
@@ -764,9 +769,9 @@ RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w)
 RT_HD void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& p0, uint32_t& p1) {
     const WalkNode N = S.bvh[w.i];
     const bool go = p1 == RT_BVH_NONE;
-    const bool hit = node_hit(N, inv, oi, tmin, w.tmax) && go && w.i < S.n_bvh_nodes;
-    const bool on_leaf = hit && N.prim != RT_BVH_NONE;
-    const uint32_t next = (hit && N.prim == RT_BVH_NONE) ? w.i + 1 : N.skip;
+    const bool hit = node_hit(N, inv, oi, tmin, w.tmax) && go;
+    const bool on_leaf = hit && N.prim >= RT_NODE_LEAF;
+    const uint32_t next = (hit && !on_leaf) ? N.prim : N.skip;  // (on the sentinel both are the sentinel)
     const bool first = p0 == RT_BVH_NONE;
     p1 = (on_leaf && !first) ? w.i : p1;
     p0 = (on_leaf && first) ? w.i : p0;

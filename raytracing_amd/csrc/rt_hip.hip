@@ -446,7 +446,7 @@ static rt_status validate_desc(const rt_scene_desc* D) {
     if (!D) return fail(RT_ERR_INVALID_ARGUMENT, "scene description is null");
     if (D->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "abi_version mismatch");
     if (D->n_prims == 0) return fail(RT_ERR_EMPTY_SCENE, "a scene needs at least one object (Scene::new asserts this)");
-    if (D->n_prims >= (1u << 29)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
+    if (D->n_prims >= (1u << 26)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");  // (node indices stay below RT_NODE_LEAF)
     if (!D->prims || !D->materials || D->n_materials == 0) return fail(RT_ERR_INVALID_ARGUMENT, "prims / materials missing");
     if ((D->n_spheres && !D->spheres) || (D->n_rects && !D->rects) || (D->n_boxes && !D->boxes) || (D->n_xforms && !D->xforms) ||
         (D->n_textures && !D->textures) || (D->n_images && !D->images) || (D->n_perm_tables && !D->perm_tables) || (D->n_bvh_nodes && !D->bvh))

@@ -311,7 +311,7 @@ def _walk_nodes(sc):
 def test_walk_node_array_keeps_the_reference_leaf_order(earth):
     """The node array the kernels walk (pruned inner nodes, paired bounds, payload slots, sentinel): same leaves in the same
     order as the tree that crosses the ABI, nested subtrees, inner boxes containing everything below them, fewer nodes."""
-    PRIM_MASK, PLAIN_BOX, PLAIN_SPHERE = 0x1FFFFFFF, 0x40000000, 0x20000000
+    PRIM_MASK, LEAF, PLAIN_BOX, PLAIN_SPHERE = 0x0FFFFFFF, 0x10000000, 0x40000000, 0x20000000
     for name in EXAMPLES:
         sc, _ = _example(name, earth)
         d = sc.desc
@@ -319,12 +319,12 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
         f = raw[:, :6].view(np.float32)
         skip, prim = raw[:, 6], raw[:, 7]
         n = len(raw) - 1
-        assert skip[n] == n and prim[n] == _abi.RT_BVH_NONE            # sentinel
+        assert skip[n] == n and prim[n] == n                            # sentinel: both links to itself
         is_payload = np.zeros(n + 2, bool)
         tight = f.copy()   # the boxes that have to nest: a node's own box, for exact leaves the exact box of the payload slot
         leaves, i = [], 0
         while i < n:                                                     # every slot is a node or the payload of the sphere leaf before it
-            if prim[i] != _abi.RT_BVH_NONE:
+            if prim[i] >= LEAF:
                 leaves.append(int(prim[i] & PRIM_MASK))
                 P = d.prims[leaves[-1]]
                 if prim[i] & PLAIN_SPHERE:
@@ -357,7 +357,7 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
                     assert not (prim[i] & PLAIN_BOX)
                     assert skip[i] == i + 1
             i += 1
-        assert leaves == [d.bvh[k].prim & PRIM_MASK for k in range(d.n_bvh_nodes) if d.bvh[k].prim != _abi.RT_BVH_NONE]
+        assert leaves == [d.bvh[k].prim & 0x1FFFFFFF for k in range(d.n_bvh_nodes) if d.bvh[k].prim != _abi.RT_BVH_NONE]
         nodes = [k for k in range(n) if not is_payload[k]]
         assert len(nodes) <= d.n_bvh_nodes
         if name == "final_scene":
@@ -366,7 +366,7 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
             assert k < skip[k] <= n
             keep = ~is_payload[k + 1:skip[k]]
             if keep.any():
-                assert prim[k] == _abi.RT_BVH_NONE
+                assert prim[k] == k + 1                                 # inner: the index of its first child
                 assert skip[k + 1:skip[k]][keep].max() <= skip[k]
                 sub = tight[k + 1:skip[k]][keep]
                 assert (f[k, 0::2] <= sub[:, 0::2].min(axis=0)).all() and (f[k, 1::2] >= sub[:, 1::2].max(axis=0)).all()
@@ -379,7 +379,7 @@ def test_wrapped_sphere_leaves_carry_the_centre_in_the_outer_frame():
     shape = rt.Shape.Sphere((3.0, 1.0, -2.0), 1.5).rotated(1, 30.0).translated((10.0, -4.0, 7.0)).rotated(0, -70.0)
     sc = rt.Scene([rt.Object(shape, rt.Material.Lambertian(rt.Texture.SolidColor((0.5, 0.5, 0.5))))], (0, 0, 0))
     raw = _walk_nodes(sc)
-    k = [i for i in range(len(raw) - 1) if raw[i, 7] != _abi.RT_BVH_NONE and (raw[i, 7] & 0x1FFFFFFF) == 0][0]
+    k = [i for i in range(len(raw) - 1) if raw[i, 7] >= 0x10000000 and (raw[i, 7] & 0x0FFFFFFF) == 0][0]
     c = raw[k + 1].view(np.float64)
     p = np.array([3.0, 1.0, -2.0])
     a = np.radians(30.0); p = np.array([p[2] * np.sin(a) + p[0] * np.cos(a), p[1], p[2] * np.cos(a) - p[0] * np.sin(a)])   # rotate Y (geometry.rs:33-50)
