@@ -766,17 +766,25 @@ RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w)
 // bound not yet lowered only visits nodes it might have skipped, and a leaf reached that way fails its test (its
 // primitive lies inside its box, beyond the bound; exact leaves repeat their box test when they are tried).
 // A walk with two leaves pending, or one that has left the tree (w.i == S.n_bvh_nodes, the sentinel slot), stays as it is.
-RT_HD void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& p0, uint32_t& p1) {
+#if defined(__HIPCC__)
+// m0 / m1: the lanes of the wave whose p0 / p1 hold a leaf (p0 != RT_BVH_NONE, p1 != RT_BVH_NONE), kept as wave masks by
+// the caller over a run of steps.  All of a step's conditions are formed as wave masks from its two comparisons
+// (mask arithmetic runs on the scalar unit), so a step spends its vector instructions on the slab test and four selects.
+__device__ __forceinline__ void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& p0, uint32_t& p1, unsigned long long& m0, unsigned long long& m1) {
     const WalkNode N = S.bvh[w.i];
-    const bool go = p1 == RT_BVH_NONE;
-    const bool hit = node_hit(N, inv, oi, tmin, w.tmax) && go;
-    const bool on_leaf = hit && N.prim >= RT_NODE_LEAF;
-    const uint32_t next = (hit && !on_leaf) ? N.prim : N.skip;  // (on the sentinel both are the sentinel)
-    const bool first = p0 == RT_BVH_NONE;
-    p1 = (on_leaf && !first) ? w.i : p1;
-    p0 = (on_leaf && first) ? w.i : p0;
-    w.i = go ? next : w.i;
+    const F2 x = fma2(N.x0, N.x1, inv.x, -oi.x), y = fma2(N.y0, N.y1, inv.y, -oi.y), z = fma2(N.z0, N.z1, inv.z, -oi.z);
+    const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), tmin));
+    const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), w.tmax));
+    const unsigned long long hit_m = __builtin_amdgcn_ballot_w64(tn <= tf) & ~m1;
+    const unsigned long long leaf_m = __builtin_amdgcn_ballot_w64(N.prim >= RT_NODE_LEAF) & hit_m;
+    const uint32_t next = __builtin_amdgcn_inverse_ballot_w64(hit_m & ~leaf_m) ? N.prim : N.skip;  // (on the sentinel both are the sentinel)
+    p1 = __builtin_amdgcn_inverse_ballot_w64(leaf_m & m0) ? w.i : p1;
+    p0 = __builtin_amdgcn_inverse_ballot_w64(leaf_m & ~m0) ? w.i : p0;
+    w.i = __builtin_amdgcn_inverse_ballot_w64(m1) ? w.i : next;
+    m1 |= leaf_m & m0;
+    m0 |= leaf_m;
 }
+#endif
 
 // The primitive test of the leaf at node w.leaf_node: Object::scatter's intersect (lib.rs:284-285) behind the
 // leaf's own bounding-box test (lib.rs:236-240).  walk_leaf_fast handles the leaves that need nothing but the
