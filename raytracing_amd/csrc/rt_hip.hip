@@ -192,12 +192,13 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             if (exhausted) break;
             continue;
         }
-        const unsigned long long pending = __ballot(active && p0 != RT_BVH_NONE);
-        const unsigned long long runnable = __ballot(active && p1 == RT_BVH_NONE && node < n_nodes);
+        // (every ballot is of one comparison, the rest is mask arithmetic on the scalar unit)
+        const unsigned long long pending = act & __ballot(p0 != RT_BVH_NONE);
+        const unsigned long long runnable = act & __ballot(p1 == RT_BVH_NONE) & __ballot(node < n_nodes);
         const unsigned long long stuck = act & ~runnable & pending;  // two leaves pending, or out of the tree with one
         if (runnable != 0ull && (uint32_t)__popcll(pending) < RT_LEAF_BATCH && (uint32_t)__popcll(stuck) < RT_STUCK_MAX) {
             Walk w; w.i = node; w.tmax = t_end;
-            unsigned long long m0 = __ballot(p0 != RT_BVH_NONE), m1 = __ballot(p1 != RT_BVH_NONE);
+            unsigned long long m0 = __ballot(p0 != RT_BVH_NONE), m1 = ~__ballot(p1 == RT_BVH_NONE);
 #pragma unroll
             for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, p0, p1, m0, m1);
             node = w.i;
