@@ -311,11 +311,11 @@ RT_HD bool box_sides_q(const DevBox& B, V3 o, V3 d, const float* q, float tmin, 
         box_side<float>(B, k, axis, x0, y0, x1, y1, h, h_lo);
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
         const float t = q[k];
-        if (t < tmin || t > tmax) continue;
-        V3 pt = ray_at(o, d, t);
-        float a = comp(pt, p1), b = comp(pt, p2);
-        if (a < x0 || a > x1 || b < y0 || b > y1) continue;
-        tmax = t; t_out = t; side = k; any = true;
+        const V3 pt = ray_at(o, d, t);
+        const float a = comp(pt, p1), b = comp(pt, p2);
+        // no branches: the six sides run as straight code, their conditions as flags
+        const bool ok = !(t < tmin || t > tmax) && !(a < x0 || a > x1 || b < y0 || b > y1);
+        tmax = ok ? t : tmax; t_out = ok ? t : t_out; side = ok ? k : side; any = any || ok;
     }
     return any;
 }
