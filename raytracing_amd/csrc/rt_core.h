@@ -114,7 +114,8 @@ RT_HD float medium_variate(const DrawKey& k, uint32_t prim) {
 // --------------------------------------------------------------- the scene
 struct SceneView {
     const rt_prim* prims; const rt_sphere* spheres; const struct DevRect* rects; const struct DevBox* boxes; const rt_xform* xforms;  // rects, boxes: make_device_shapes
-    const rt_material* materials; const rt_texture* textures; const rt_image* images; const uint8_t* texels;
+    const struct ShadeRec* shade;  // per primitive: the primitive and its material side by side (make_shade_records)
+    const rt_texture* textures; const rt_image* images; const uint8_t* texels;
     const uint8_t* perm; const struct WalkNode* bvh;  // bvh: n_bvh_nodes slots and one sentinel slot (make_walk_nodes)
     uint32_t n_prims, n_bvh_nodes;
     float background[3];
@@ -944,6 +945,46 @@ RT_HD float schlick(float cosine, float ri) {  // materials.rs:143
 
 struct Scatter { bool scattered; V3 color; V3 o, d; };  // RayHit (lib.rs:300-306)
 
+// Bits of rt_material.reserved[0] that the library sets on its own copy of the materials (make_shade_records):
+//   RT_MAT_SKIP_UV       no texture this material can reach reads the surface coordinates (u, v), so shading need not
+//                        compute them;
+//   RT_MAT_SOLID_INLINE  the material's texture is a SolidColor, whose colour stands in `albedo` (textured materials
+//                        have no albedo of their own), so shading need not fetch the texture.
+#define RT_MAT_SKIP_UV 1u
+#define RT_MAT_SOLID_INLINE 2u
+// The primitive and its material in one 64-byte record: shading reads both with one fetch instead of one after the other.
+struct ShadeRec { rt_prim prim; rt_material mat; };
+static_assert(sizeof(ShadeRec) == 64, "shading record size");
+// (host side) the records of a scene description
+inline void make_shade_records(const rt_scene_desc* D, std::vector<ShadeRec>& out) {
+    std::vector<rt_material> mats(D->materials, D->materials + D->n_materials);
+    for (auto& M : mats) {
+        bool reads_uv = false;
+        M.reserved[0] &= ~(RT_MAT_SKIP_UV | RT_MAT_SOLID_INLINE);
+        if (M.kind == RT_MAT_LAMBERTIAN || M.kind == RT_MAT_DIFFUSE_LIGHT || M.kind == RT_MAT_ISOTROPIC) {
+            const rt_texture& T0 = D->textures[M.texture];
+            if (T0.kind == RT_TEX_SOLID) { M.reserved[0] |= RT_MAT_SOLID_INLINE; for (int c = 0; c < 3; ++c) M.albedo[c] = T0.color[c]; }
+            std::vector<uint32_t> todo{M.texture};  // image textures are the only kind that reads (u, v)
+            for (uint32_t depth = 0; depth <= RT_MAX_TEXTURE_NESTING && !todo.empty() && !reads_uv; ++depth) {
+                std::vector<uint32_t> next;
+                for (uint32_t t : todo) {
+                    const rt_texture& T = D->textures[t];
+                    if (T.kind == RT_TEX_IMAGE) reads_uv = true;
+                    else if (T.kind == RT_TEX_CHECKERED) { next.push_back(T.odd); next.push_back(T.even); }
+                }
+                todo.swap(next);
+            }
+        }
+        if (!reads_uv) M.reserved[0] |= RT_MAT_SKIP_UV;
+    }
+    out.resize(D->n_prims);
+    for (uint32_t i = 0; i < D->n_prims; ++i) { out[i].prim = D->prims[i]; out[i].mat = mats[D->prims[i].material]; }
+}
+RT_HD V3 material_color(const SceneView& S, const rt_material& M, const Hit& h) {
+    if (M.reserved[0] & RT_MAT_SOLID_INLINE) return v3(M.albedo[0], M.albedo[1], M.albedo[2]);
+    return texture_color(S, M.texture, h.u, h.v, h.point);
+}
+
 // Material::scatter (materials.rs:28-114) with the draws of stream 0 of the segment.
 RT_HD Scatter material_scatter(const SceneView& S, const rt_material& M, const Hit& h, const DrawKey& key) {
     const U4 rnd = philox4x32_10(key.pixel, key.sample, key.bounce, 0u, key.k0, key.k1);
@@ -960,7 +1001,7 @@ RT_HD Scatter material_scatter(const SceneView& S, const rt_material& M, const H
         // within an f64 ulp of 1), 0 for cos < 0, NaN for cos = 0; the sign of cos is the sign of normal . direction
         double proj = dot(nd, dir);
         float w = proj > 0.0 ? 1.0f : (proj < 0.0 ? -0.0f : RT_NAN_F);
-        V3 tex = texture_color(S, M.texture, h.u, h.v, h.point);
+        V3 tex = material_color(S, M, h);
         out.color = tex * w;
         out.scattered = true; out.d = v3(dir);
     } else if (M.kind == RT_MAT_METAL) {
@@ -979,20 +1020,17 @@ RT_HD Scatter material_scatter(const SceneView& S, const rt_material& M, const H
         else dir = refract(in_unit, h.normal, eta);
         out.scattered = true; out.color = v3(M.albedo[0], M.albedo[1], M.albedo[2]); out.d = dir;
     } else if (M.kind == RT_MAT_DIFFUSE_LIGHT) {
-        out.scattered = false; out.color = texture_color(S, M.texture, h.u, h.v, h.point);
+        out.scattered = false; out.color = material_color(S, M, h);
     } else {  // Isotropic
         out.scattered = true; out.d = random_unit_vector(u01(rnd.x), u01(rnd.y));
-        out.color = texture_color(S, M.texture, h.u, h.v, h.point);
+        out.color = material_color(S, M, h);
     }
     return out;
 }
 RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& key) {
-    return material_scatter(S, S.materials[S.prims[h.prim].material], h, key);
+    return material_scatter(S, S.shade[h.prim].mat, h, key);
 }
 
-// Bit of rt_material.reserved[0] that the library sets on its own copy of the materials: no texture this material
-// can reach reads the surface coordinates (u, v), so shading need not compute them.
-#define RT_MAT_SKIP_UV 1u
 
 // One step of ray_color (lib.rs:89-101) for a ray whose closest hit is known.
 // Returns true when the path continues (r and thr updated); otherwise `value` is the
@@ -1000,8 +1038,9 @@ RT_HD Scatter material_scatter(const SceneView& S, const Hit& h, const DrawKey& 
 RT_HD bool shade_step(const SceneView& S, Ray& r, V3& thr, const DrawKey& key, bool hit, float t, uint32_t prim, int side, bool last_bounce, V3& value) {
     if (!hit) { value = thr * v3(S.background[0], S.background[1], S.background[2]); return false; }  // lib.rs:91
     Hit h;
-    const rt_prim P = S.prims[prim];
-    const rt_material M = S.materials[P.material];
+    const ShadeRec R = S.shade[prim];
+    const rt_prim P = R.prim;
+    const rt_material M = R.mat;
     prim_surface(S, P, prim, r.o, r.d, r.time, t, side, !(M.reserved[0] & RT_MAT_SKIP_UV), M.kind == RT_MAT_METAL || M.kind == RT_MAT_DIELECTRIC, h);
     Scatter sc = material_scatter(S, M, h, key);
     if (!sc.scattered) { value = thr * sc.color; return false; }  // lib.rs:92

@@ -574,25 +574,10 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         UP(boxes, boxes.data(), boxes.size());
     }
     UP(xforms, D->xforms, D->n_xforms);
-    {   // materials, with RT_MAT_SKIP_UV where no reachable texture is an image (the only kind that reads (u, v))
-        std::vector<rt_material> mats(D->materials, D->materials + D->n_materials);
-        for (auto& M : mats) {
-            bool reads_uv = false;
-            if (M.kind == RT_MAT_LAMBERTIAN || M.kind == RT_MAT_DIFFUSE_LIGHT || M.kind == RT_MAT_ISOTROPIC) {
-                std::vector<uint32_t> todo{M.texture};
-                for (uint32_t depth = 0; depth <= RT_MAX_TEXTURE_NESTING && !todo.empty() && !reads_uv; ++depth) {
-                    std::vector<uint32_t> next;
-                    for (uint32_t t : todo) {
-                        const rt_texture& T = D->textures[t];
-                        if (T.kind == RT_TEX_IMAGE) reads_uv = true;
-                        else if (T.kind == RT_TEX_CHECKERED) { next.push_back(T.odd); next.push_back(T.even); }
-                    }
-                    todo.swap(next);
-                }
-            }
-            if (reads_uv) M.reserved[0] &= ~RT_MAT_SKIP_UV; else M.reserved[0] |= RT_MAT_SKIP_UV;
-        }
-        UP(materials, mats.data(), mats.size());
+    {   // the primitives again, each with its material beside it (flags set, solid colours inlined)
+        std::vector<ShadeRec> recs;
+        make_shade_records(D, recs);
+        UP(shade, recs.data(), recs.size());
     }
     UP(textures, D->textures, D->n_textures);
     UP(images, D->images, D->n_images);

@@ -29,11 +29,13 @@ struct TwinScene {
     std::vector<WalkNode> nodes;
     std::vector<DevRect> rects;
     std::vector<DevBox> boxes;
+    std::vector<ShadeRec> shade;
     // with_nodes = false: for callers that never walk the tree (the node array takes some milliseconds to make)
     explicit TwinScene(const rt_scene_desc* D, bool with_nodes = true) {
         make_device_shapes(D, rects, boxes);
         V.prims = D->prims; V.spheres = D->spheres; V.rects = rects.data(); V.boxes = boxes.data(); V.xforms = D->xforms;
-        V.materials = D->materials; V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
+        make_shade_records(D, shade);
+        V.shade = shade.data(); V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
         if (with_nodes) make_walk_nodes(D, nodes);
         V.bvh = nodes.data();
         V.n_prims = D->n_prims; V.n_bvh_nodes = with_nodes ? (uint32_t)nodes.size() - 1 : 0;
