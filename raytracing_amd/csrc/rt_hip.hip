@@ -135,6 +135,15 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #ifndef RT_STEPS_PER_TURN
 #define RT_STEPS_PER_TURN 10  // node steps between two looks at the wave's state
 #endif
+#ifdef RT_TRAV_STATS
+// Analysis build only: what the waves of k_traverse spend their turns on (summed over all launches since the last read).
+// 0 step turns, 1 lanes that could step at the start of a step turn, 2 leaf turns, 3 lanes with a leaf pending at a leaf turn,
+// 4 sphere leaves tried, 5 box leaves tried, 6 other leaves tried, 7 leaf turns that ran more than one kind, 8 refills, 9 rays taken
+__device__ unsigned long long g_trav_stats[16];
+#define RT_STAT(k, v) do { if (lane == 0) st[k] += (v); } while (0)
+#else
+#define RT_STAT(k, v)
+#endif
 template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LDS ? 6 : 1) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
                                                                                    uint2* hits, uint32_t bounce) {
@@ -154,6 +163,9 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
     if (threadIdx.x == 0) next_ray = 0;
     __syncthreads();
 
+#ifdef RT_TRAV_STATS
+    unsigned long long st[16] = {};
+#endif
     bool active = false, exhausted = n_nodes == 0;
     Ray r; r.o = v3(0, 0, 0); r.d = v3(1, 1, 1); r.time = 0.0f;
     V3 inv = v3(1, 1, 1), oi = v3(0, 0, 0);
@@ -175,6 +187,9 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             exhausted = base + n_idle >= my_rays;
             const uint32_t local = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t mine = ((local / RT_TRAV_GROUP) * gridDim.x + blockIdx.x) * RT_TRAV_GROUP + local % RT_TRAV_GROUP;
+#ifdef RT_TRAV_STATS
+            { const uint32_t taken = (uint32_t)__popcll(__ballot(!active && local < my_rays && mine < count)); RT_STAT(8, 1); RT_STAT(9, taken); }
+#endif
             if (!active && local < my_rays && mine < count) {
                 const uint32_t at = queue_slot(mine, n_front, P.n_paths);
                 const float4 a = q.od0[at];
@@ -197,12 +212,22 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
         const unsigned long long runnable = act & __ballot(p1 == RT_BVH_NONE) & __ballot(node < n_nodes);
         const unsigned long long stuck = act & ~runnable & pending;  // two leaves pending, or out of the tree with one
         if (runnable != 0ull && (uint32_t)__popcll(pending) < RT_LEAF_BATCH && (uint32_t)__popcll(stuck) < RT_STUCK_MAX) {
+            RT_STAT(0, 1); RT_STAT(1, (uint32_t)__popcll(runnable));
             Walk w; w.i = node; w.tmax = t_end;
             unsigned long long m0 = __ballot(p0 != RT_BVH_NONE), m1 = ~__ballot(p1 == RT_BVH_NONE);
 #pragma unroll
             for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, p0, p1, m0, m1);
             node = w.i;
         } else {
+#ifdef RT_TRAV_STATS
+            {
+                const uint32_t lf = (active && p0 != RT_BVH_NONE) ? S.bvh[p0].prim : 0u;
+                const uint32_t ns = (uint32_t)__popcll(__ballot((lf & RT_NODE_PLAIN_SPHERE) != 0)), nb = (uint32_t)__popcll(__ballot((lf & RT_NODE_PLAIN_BOX) != 0));
+                const uint32_t np = (uint32_t)__popcll(pending);
+                RT_STAT(2, 1); RT_STAT(3, np); RT_STAT(4, ns); RT_STAT(5, nb); RT_STAT(6, np - ns - nb);
+                RT_STAT(7, ((ns != 0) + (nb != 0) + (np - ns - nb != 0)) > 1 ? 1 : 0);
+            }
+#endif
             if (active && p0 != RT_BVH_NONE) {
                 Walk w; walk_init(w, t_end);
                 w.leaf_node = p0;
@@ -221,6 +246,9 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             active = false;
         }
     }
+#ifdef RT_TRAV_STATS
+    if (lane == 0) for (int k = 0; k < 16; ++k) if (st[k]) atomicAdd(&g_trav_stats[k], st[k]);
+#endif
 }
 
 // Workgroup size of k_shade.  Each workgroup pass ends in one atomic on the length of the next queue; at 256 threads
@@ -920,6 +948,16 @@ rt_status rt_render(rt_scene* sc, const rt_camera* cam, const rt_image_options* 
     if (d_rgb) (void)hipFree(d_rgb);
     return st;
 }
+
+#ifdef RT_TRAV_STATS
+// Analysis build only: reads and clears the turn statistics of k_traverse.
+rt_status rt_debug_trav_stats(unsigned long long* out16) {
+    unsigned long long zero[16] = {};
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trav_stats), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, sizeof(zero)));
+    return RT_OK;
+}
+#endif
 
 rt_status rt_get_profile(rt_scene* sc, rt_profile* out) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");

@@ -1,0 +1,23 @@
+"""Analysis: what the waves of k_traverse spend their turns on (needs librt_hip.so built with -DRT_TRAV_STATS).
+final_scene 800x800 at 16 spp, wavefront kernels only, one stream."""
+import ctypes as C
+import sys
+sys.path.insert(0, '.')
+import raytracing_amd as rt
+from raytracing_amd import _abi
+lib = C.CDLL(_abi.HIP_LIB_PATH)
+sc, co = rt.Scene.example('final_scene', 1, rt.earthmap()); cam = rt.Camera(co)
+out = (C.c_ulonglong * 16)()
+lib.rt_debug_trav_stats(out)
+sc.render(cam, rt.ImageOptions(800, 800, 16, 50), rt.RenderOptions(seed=1, flags=1 | 2 | 16))
+seg = sc.profile()['segments']
+assert lib.rt_debug_trav_stats(out) == 0
+s = list(out)
+names = ['step turns', 'lanes able to step at a step turn', 'leaf turns', 'lanes with a leaf at a leaf turn', 'sphere leaves', 'box leaves', 'other leaves',
+         'leaf turns with more than one kind', 'refills', 'rays taken']
+for n, v in zip(names, s):
+    print('%-40s %14d  per segment %.4f' % (n, v, v / seg))
+print('segments', seg)
+print('lanes able to step per step turn: %.1f of 64' % (s[1] / s[0]))
+print('lanes with a leaf per leaf turn: %.1f (sphere %.1f, box %.1f, other %.2f); turns with more than one kind: %.1f %%' % (s[3] / s[2], s[4] / s[2], s[5] / s[2], s[6] / s[2], 100 * s[7] / s[2]))
+print('rays per refill: %.1f' % (s[9] / s[8]))
