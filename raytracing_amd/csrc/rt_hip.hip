@@ -228,17 +228,24 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
                 RT_STAT(7, ((ns != 0) + (nb != 0) + (np - ns - nb != 0)) > 1 ? 1 : 0);
             }
 #endif
-            if (active && p0 != RT_BVH_NONE) {
-                Walk w; walk_init(w, t_end);
-                w.leaf_node = p0;
-                const uint32_t leaf = S.bvh[p0].prim;
-                if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) {  // only these leaves need the ray's time (moving spheres) and the path and pixel numbers (they key a medium's draw)
-                    const float4 b = q.od1[slot];
-                    r.time = b.z;
-                    walk_leaf_generic(S, r, tmin, make_key(P, __float_as_uint(b.w), __float_as_uint(q.thr[slot].w), bounce), leaf, w);
+            // Two rounds: first the lanes whose oldest leaf is a sphere, then those whose oldest leaf (by now) is anything
+            // else.  A wave runs both kinds of test in nearly every turn anyway (its lanes hold both kinds); this way a lane
+            // with a sphere and then a box pending has both tried in one turn, in their order.
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const bool has = active && p0 != RT_BVH_NONE;
+                const uint32_t leaf = has ? S.bvh[p0].prim : 0u;
+                if (has && ((leaf & RT_NODE_PLAIN_SPHERE) != 0u) == (round == 0)) {
+                    Walk w; walk_init(w, t_end);
+                    w.leaf_node = p0;
+                    if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) {  // only these leaves need the ray's time (moving spheres) and the path and pixel numbers (they key a medium's draw)
+                        const float4 b = q.od1[slot];
+                        r.time = b.z;
+                        walk_leaf_generic(S, r, tmin, make_key(P, __float_as_uint(b.w), __float_as_uint(q.thr[slot].w), bounce), leaf, w);
+                    }
+                    if (w.found) { t_end = w.t; best = w.prim | ((uint32_t)w.side << 29); }
+                    p0 = p1; p1 = RT_BVH_NONE;
                 }
-                if (w.found) { t_end = w.t; best = w.prim | ((uint32_t)w.side << 29); }
-                p0 = p1; p1 = RT_BVH_NONE;
             }
         }
         if (active && p0 == RT_BVH_NONE && node >= n_nodes) {
