@@ -309,7 +309,7 @@ def _walk_nodes(sc):
 
 
 def test_walk_node_array_keeps_the_reference_leaf_order(earth):
-    """The node array the kernels walk (pruned inner nodes, paired bounds, payload slots, sentinel): same leaves in the same
+    """The node array the kernels walk (regrouped inner nodes, paired bounds, payload slots, sentinel): same leaves in the same
     order as the tree that crosses the ABI, nested subtrees, inner boxes containing everything below them, fewer nodes."""
     PRIM_MASK, LEAF, PLAIN_BOX, PLAIN_SPHERE = 0x0FFFFFFF, 0x10000000, 0x40000000, 0x20000000
     for name in EXAMPLES:
