@@ -138,7 +138,8 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #ifdef RT_TRAV_STATS
 // Analysis build only: what the waves of k_traverse spend their turns on (summed over all launches since the last read).
 // 0 step turns, 1 lanes that could step at the start of a step turn, 2 leaf turns, 3 lanes with a leaf pending at a leaf turn,
-// 4 sphere leaves tried, 5 box leaves tried, 6 other leaves tried, 7 leaf turns that ran more than one kind, 8 refills, 9 rays taken
+// 4 / 5 / 6 lanes whose oldest leaf is a sphere / a box / something else at a leaf turn, 7 leaf turns that hold more than one kind,
+// 8 refills, 9 rays taken, 10 / 11 leaves tried in the first / second round of the leaf turns
 __device__ unsigned long long g_trav_stats[16];
 #define RT_STAT(k, v) do { if (lane == 0) st[k] += (v); } while (0)
 #else
@@ -235,6 +236,9 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             for (int round = 0; round < 2; ++round) {
                 const bool has = active && p0 != RT_BVH_NONE;
                 const uint32_t leaf = has ? S.bvh[p0].prim : 0u;
+#ifdef RT_TRAV_STATS
+                { const uint32_t served = (uint32_t)__popcll(__ballot(has && ((leaf & RT_NODE_PLAIN_SPHERE) != 0u) == (round == 0))); RT_STAT(10 + round, served); }
+#endif
                 if (has && ((leaf & RT_NODE_PLAIN_SPHERE) != 0u) == (round == 0)) {
                     Walk w; walk_init(w, t_end);
                     w.leaf_node = p0;
