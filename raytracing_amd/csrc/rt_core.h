@@ -235,6 +235,27 @@ RT_HD double rsqrt_near(double x) { return 1.0 / sqrt(x); }
 RT_HD V3 ray_inv(V3 d) { return v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 RT_HD void sincos_turns(float u, float& s, float& c) { const float phi = (2.0f * RT_PI_F) * u; s = sinf(phi); c = cosf(phi); }
 #endif
+// The walk's node test forms (bound * inv - origin * inv); with an infinite inv (a zero direction component) that is
+// inf - inf = NaN for every bound on the origin's side of zero, and the test would take the slab for unbounded where the
+// reference (shape.rs:584-588: (bound - origin) / 0 = +-inf) sees the ray pass beside the box.  The walk therefore caps
+// |inv| at 2^100: the products stay finite for coordinates up to 1e8 and keep the signs of (bound - origin), and any
+// finite capped quotient is beyond every hit.  NaN stays NaN (a NaN direction component makes the reference ignore the
+// axis).  The leaf tests get the infinity back (walk_uncap): they follow the reference's quotients literally.
+#define RT_INV_CAP 1.2676506002282294e30f
+// A capped quotient is finite where the reference has +inf; a slab whose near end is there is missed by the reference
+// (tmax <= tmin with both infinite, shape.rs:593), so the node tests run against min(tmax, 2^90): no hit lies beyond.
+#define RT_WALK_FAR 1.2379400392853803e27f
+RT_HD float cap_inv(float r) { return fabsf(r) > RT_INV_CAP ? copysignf(RT_INV_CAP, r) : r; }
+RT_HD float uncap_inv(float c) { return fabsf(c) == RT_INV_CAP ? copysignf(RT_INF_F, c) : c; }
+// A direction component of -0.0: the reference swaps a slab's two quotients only for d < 0.0 (shape.rs:586), which -0.0
+// is not, so the quotients (bound - origin) / -0.0 = -+inf stay in the order (far, near) and every bounding box with an
+// extent on that axis is missed: such a ray hits nothing that stands behind a bounding-box test (everything in a scene).
+RT_HD bool has_negative_zero(V3 d) {
+    uint32_t x, y, z; memcpy(&x, &d.x, 4); memcpy(&y, &d.y, 4); memcpy(&z, &d.z, 4);
+    return x == 0x80000000u || y == 0x80000000u || z == 0x80000000u;
+}
+RT_HD V3 walk_cap(V3 inv) { return v3(cap_inv(inv.x), cap_inv(inv.y), cap_inv(inv.z)); }
+RT_HD V3 walk_uncap(V3 inv) { return v3(uncap_inv(inv.x), uncap_inv(inv.y), uncap_inv(inv.z)); }
 // Near root (-half_b - sqrt(disc)) / a of shape.rs:262-270; false when the discriminant is negative.
 RT_HD bool sphere_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time, double& t_out) {
     D3 c = sphere_center(sp, moving, time);
@@ -755,7 +776,7 @@ RT_HD bool node_hit(const WalkNode& N, V3 inv, V3 oi, float tmin, float tmax) {
 RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w) {
     const WalkNode N = S.bvh[w.i];
     RT_COUNT(nodes);
-    if (!node_hit(N, inv, oi, tmin, w.tmax)) { w.i = N.skip; return RT_BVH_NONE; }
+    if (!node_hit(N, inv, oi, tmin, fminf(w.tmax, RT_WALK_FAR))) { w.i = N.skip; return RT_BVH_NONE; }
     w.leaf_node = w.i;
     if (N.prim < RT_NODE_LEAF) { w.i = N.prim; return RT_BVH_NONE; }  // inner: on to its first child
     w.i = N.skip;  // a leaf's skip link also jumps over its payload slot, if any
@@ -791,7 +812,8 @@ __device__ __forceinline__ void walk_step_flat(const SceneView& S, V3 inv, V3 oi
 // leaf's own bounding-box test (lib.rs:236-240).  walk_leaf_fast handles the leaves that need nothing but the
 // node array (and no random draw) and returns false for the rest, which walk_leaf_generic takes.
 RT_HD void walk_accept(Walk& w, float t, uint32_t prim, int side) { w.tmax = t; w.t = t; w.prim = prim; w.side = side; w.found = true; }
-RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, uint32_t leaf, Walk& w) {
+// `inv_capped`: 1 / direction as the walk holds it (see walk_cap); only the box leaves use it.
+RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv_capped, float tmin, uint32_t leaf, Walk& w) {
     const uint32_t prim = leaf & RT_NODE_PRIM_MASK;
     if (leaf & RT_NODE_PLAIN_SPHERE) {
         RT_COUNT(leaves); RT_COUNT(prim_tests);
@@ -811,6 +833,7 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv, float tmin, 
     DevBox B;
     for (int c = 0; c < 3; ++c) { B.min[c] = exact[c]; B.max[c] = exact[3 + c]; B.min_lo[c] = plain ? rem[c] : 0.0f; B.max_lo[c] = plain ? rem[3 + c] : 0.0f; }
     float q[6];
+    const V3 inv = walk_uncap(inv_capped);  // the reference's quotients: +-inf and NaN where a direction component is zero
     box_quotients(B, r.o, inv, q);
     float lo = tmin, hi = w.tmax;
     lo = fmaxf(r.d.x < 0.0f ? q[1] : q[0], lo); hi = fminf(r.d.x < 0.0f ? q[0] : q[1], hi);
@@ -838,15 +861,16 @@ RT_HD void walk_leaf_generic(const SceneView& S, const Ray& r, float tmin, const
 // stands on a leaf, the outer loop runs the (much longer) primitive test, so the lanes of a wave run their
 // primitive tests together, once per round.
 RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax, const DrawKey& key, float& best_t, uint32_t& best_prim, int& best_side) {
-    const V3 inv = ray_inv(r.d);
-    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+    if (has_negative_zero(r.d)) return false;
+    const V3 inv_c = walk_cap(ray_inv(r.d));
+    const V3 oi = v3(r.o.x * inv_c.x, r.o.y * inv_c.y, r.o.z * inv_c.z);
     Walk w; walk_init(w, tmax);
     const uint32_t n = S.n_bvh_nodes;
     for (;;) {
         uint32_t leaf = RT_BVH_NONE;
-        while (w.i < n && leaf == RT_BVH_NONE) leaf = walk_step(S, inv, oi, tmin, w);
+        while (w.i < n && leaf == RT_BVH_NONE) leaf = walk_step(S, inv_c, oi, tmin, w);
         if (leaf == RT_BVH_NONE) break;
-        if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, key, leaf, w);
+        if (!walk_leaf_fast(S, r, inv_c, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, key, leaf, w);
     }
     best_t = w.t; best_prim = w.prim; best_side = w.side;
     return w.found;

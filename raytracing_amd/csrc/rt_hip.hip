@@ -196,9 +196,10 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
                 const float4 a = q.od0[at];
                 const float2 b = *reinterpret_cast<const float2*>(&q.od1[at]);
                 r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y);
-                inv = ray_inv(r.d);
+                inv = walk_cap(ray_inv(r.d));  // capped for the node tests; the box leaves get the infinities back
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
-                node = 0; t_end = RT_INF_F; best = RT_HIT_NONE;
+                node = has_negative_zero(r.d) ? n_nodes : 0u;  // (such a ray misses every bounding box: it is done at once)
+                t_end = RT_INF_F; best = RT_HIT_NONE;
                 slot = at; p0 = RT_BVH_NONE; p1 = RT_BVH_NONE;
                 active = true;
             }
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
         const unsigned long long stuck = act & ~runnable & pending;  // two leaves pending, or out of the tree with one
         if (runnable != 0ull && (uint32_t)__popcll(pending) < RT_LEAF_BATCH && (uint32_t)__popcll(stuck) < RT_STUCK_MAX) {
             RT_STAT(0, 1); RT_STAT(1, (uint32_t)__popcll(runnable));
-            Walk w; w.i = node; w.tmax = t_end;
+            Walk w; w.i = node; w.tmax = fminf(t_end, RT_WALK_FAR);
             unsigned long long m0 = __ballot(p0 != RT_BVH_NONE), m1 = ~__ballot(p1 == RT_BVH_NONE);
 #pragma unroll
             for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, p0, p1, m0, m1);

@@ -61,30 +61,65 @@ def rays_at_box(rng, mn, mx, n, spread=1.5):
     return o.astype(np.float32), d.astype(np.float32), t.astype(np.float32)
 
 
-def compare_hits(got, ref, what="", tol=TOL, allow_flag_mismatch=0.0, allow_prim_mismatch=0.0, origins=None):
-    """Asserts hit records `got` (rt_hit, fp32) agree with the oracle's `ref` (f64)."""
+def degenerate_rays(mn, mx):
+    """Rays that exercise the infinities, NaNs and ties of the reference's arithmetic (shape.rs:321-329, :580-599,
+    geometry.rs:340-346): origins on a 5 x 5 x 5 grid that includes the exact face coordinates of the box [mn, mx], its
+    centre and points outside; directions along the axes (zeros and negative zeros in the other components), in the
+    coordinate planes, the zero vector and one with a NaN."""
+    mn, mx = np.maximum(np.asarray(mn, float), -5000.0), np.minimum(np.asarray(mx, float), 5000.0)
+    c = 0.5 * (mn + mx)
+    axes = [np.array([mn[k] - 1.0, mn[k], c[k], mx[k], mx[k] + 1.0]) for k in range(3)]
+    o = np.array([[x, y, z] for x in axes[0] for y in axes[1] for z in axes[2]])
+    nz = -0.0
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 0, 1], [0, 1, -1], [-1, 1, 0],
+                     [nz, 1, 0.5], [1, nz, nz], [nz, nz, -1], [0, 0, 0], [np.nan, 1, 0]], dtype=float)
+    oo = np.repeat(o, len(dirs), axis=0)
+    dd = np.tile(dirs, (len(o), 1))
+    return oo.astype(np.float32), dd.astype(np.float32), np.full(len(oo), 0.5, np.float32)
+
+
+def compare_hits(got, ref, what="", tol=TOL, allow_flag_mismatch=0.0, allow_prim_mismatch=0.0, origins=None, allow_record_mismatch=0.0):
+    """Asserts hit records `got` (rt_hit, fp32) agree with the oracle's `ref` (f64).
+    allow_record_mismatch: share of the records that may differ beyond `tol` in some field (for crafted rays that
+    graze edges: which side of a box an edge hit names, and what a medium makes of it, hangs on rounding)."""
     n = len(ref)
-    flag_mis = got["hit"] != ref["hit"]
+    # An accepted NaN t (a side whose plane holds the origin of a ray parallel to it: 0 / 0 passes every comparison,
+    # shape.rs:321-329) against a number counts as a hit / miss mismatch: which of the two a grazing ray ends with
+    # hangs on the rounding of the sides tried after it.
+    nan_mis = (got["hit"] == 1) & (ref["hit"] == 1) & (np.isnan(got["t"]) != np.isnan(ref["t"]))
+    flag_mis = (got["hit"] != ref["hit"]) | nan_mis
     assert flag_mis.sum() <= allow_flag_mismatch * n, f"{what}: {int(flag_mis.sum())}/{n} hit/miss mismatches, first at {np.where(flag_mis)[0][:5]}"
-    both = (got["hit"] == 1) & (ref["hit"] == 1)
+    both = (got["hit"] == 1) & (ref["hit"] == 1) & ~nan_mis
     prim_mis = both & (got["prim"] != ref["prim"])
     assert prim_mis.sum() <= allow_prim_mismatch * n, f"{what}: {int(prim_mis.sum())}/{n} primitive mismatches, first at {np.where(prim_mis)[0][:5]}"
     same = both & ~prim_mis
-    worst = {}
+    idx = np.where(same)[0]
+    errs = {}
     for f in ("t", "point", "normal", "in_vec", "u", "v"):
         a, b = got[f][same].astype(np.float64), ref[f][same]
         scale = np.maximum(1.0, np.abs(b))
-        if f == "point":
-            scale = np.maximum(1.0, np.abs(b).max(axis=1, keepdims=True))
+        if f == "point":   # relative to the largest finite coordinate (a point may have NaN or infinite components on both sides)
+            fin = lambda x: np.where(np.isfinite(x), np.abs(x), 0.0).max(axis=1, keepdims=True)
+            scale = np.maximum(1.0, fin(b))
             if origins is not None:
-                scale = np.maximum(scale, np.abs(np.asarray(origins, np.float64)[same]).max(axis=1, keepdims=True))
+                scale = np.maximum(scale, fin(np.asarray(origins, np.float64)[same]))
         with np.errstate(invalid="ignore"):
             err = np.abs(a - b) / scale
         err[(np.isnan(a) & np.isnan(b)) | (a == b)] = 0.0   # NaN on both sides, or the same infinity
-        worst[f] = float(err.max()) if err.size else 0.0
-        assert not np.isnan(err).any(), f"{what}: NaN mismatch in {f}"
-        assert worst[f] <= tol, f"{what}: {f} off by {worst[f]:.3e} (> {tol}) at ray {np.where(same)[0][np.unravel_index(np.argmax(err), err.shape)[0]]}"
-    return int(same.sum()), worst
+        if f == "u":   # at a sphere's pole (v = 0 or 1) the longitude is the angle of a vector of rounding errors
+            v_ref = ref["v"][same]
+            err[(np.abs(v_ref) < 1e-6) | (np.abs(v_ref - 1.0) < 1e-6)] = 0.0
+        err = np.where(np.isnan(err), np.inf, err)   # NaN on one side only
+        errs[f] = err.reshape(len(idx), -1).max(axis=1) if len(idx) else np.zeros(0)
+    off = np.zeros(len(idx), bool)
+    for f in errs:
+        off |= errs[f] > tol
+    if off.sum() > allow_record_mismatch * n:
+        f = max(errs, key=lambda k: errs[k].max())
+        k = int(np.argmax(errs[f]))
+        raise AssertionError(f"{what}: {int(off.sum())}/{n} records off; worst: {f} off by {errs[f][k]:.3e} (> {tol}) at ray {idx[k]}")
+    worst = {f: float(errs[f][~off].max()) if (~off).any() else 0.0 for f in errs}
+    return int(len(idx) - off.sum()), worst
 
 
 def path_rays(oscene, oco, width, height, seed, n, bounces, rng):
