@@ -246,7 +246,8 @@ RT_HD void sincos_turns(float u, float& s, float& c) { const float phi = (2.0f *
 // (tmax <= tmin with both infinite, shape.rs:593), so the node tests run against min(tmax, 2^90): no hit lies beyond.
 #define RT_WALK_FAR 1.2379400392853803e27f
 RT_HD float cap_inv(float r) { return fabsf(r) > RT_INV_CAP ? copysignf(RT_INV_CAP, r) : r; }
-RT_HD float uncap_inv(float c) { return fabsf(c) == RT_INV_CAP ? copysignf(RT_INF_F, c) : c; }
+// (two exact scalings instead of a comparison: 2^100 * 2^28 overflows to infinity, everything below comes back unchanged)
+RT_HD float uncap_inv(float c) { return (c * 268435456.0f) * 3.7252902984619140625e-9f; }
 // A direction component of -0.0: the reference swaps a slab's two quotients only for d < 0.0 (shape.rs:586), which -0.0
 // is not, so the quotients (bound - origin) / -0.0 = -+inf stay in the order (far, near) and every bounding box with an
 // extent on that axis is missed: such a ray hits nothing that stands behind a bounding-box test (everything in a scene).
