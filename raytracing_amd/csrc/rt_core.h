@@ -519,6 +519,9 @@ struct Ray {
 //                         box test at the leaf; the box in the node is widened like every other (it only gates the visit);
 //   RT_NODE_PLAIN_BOX     exact leaf whose primitive is a box without wrappers or medium: the leaf's exact box is the
 //                         geometry, and a second slot holds the fp32 remainders of the box's f64 coordinates (see DevBox);
+//   RT_NODE_PLAIN_RECT    leaf of a Rectangle without wrappers or medium, made an exact leaf by the library: the first slot
+//                         holds the rectangle's bound() (shape.rs:457-481, computed here in f64 from the rt_rect) and the
+//                         plane's coordinate as value + remainder, the second the bound's remainders and the axis;
 //   RT_NODE_PLAIN_SPHERE  leaf of a Sphere that is not a medium's boundary: the array slot after the leaf holds
 //                         {center.x, center.y, center.z, radius} as four doubles (the leaf's skip link jumps over it).
 //                         Behind Translated / Rotated wrappers the centre is the wrapped sphere's centre carried out
@@ -527,7 +530,8 @@ struct Ray {
 // A leaf's word also has RT_NODE_LEAF set; the word of an inner node is the index of its first child (the next slot),
 // below RT_NODE_LEAF, so that a step picks its successor from the node's two words without arithmetic.
 // The slot after the last node is a sentinel (both links to itself) that a finished or idle walk may read and step on.
-#define RT_NODE_PRIM_MASK 0x0FFFFFFFu
+#define RT_NODE_PRIM_MASK 0x07FFFFFFu
+#define RT_NODE_PLAIN_RECT 0x08000000u
 #define RT_NODE_LEAF 0x10000000u
 #define RT_NODE_PLAIN_BOX 0x40000000u
 #define RT_NODE_PLAIN_SPHERE 0x20000000u
@@ -693,8 +697,13 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
         for (int c = 0; c < 3; ++c) same = same && (float)B.min[c] == N.min[c] && (float)B.max[c] == N.max[c];
         return same;
     };
-    auto exact_leaf = [&](const rt_bvh_node& N) { return N.prim != RT_BVH_NONE && (N.prim & RT_BVH_EXACT) != 0; };
-    auto payload_slots = [&](const rt_bvh_node& N) { return plain_sphere(N) ? 1u : (plain_box(N) ? 2u : (exact_leaf(N) ? 1u : 0u)); };
+    auto plain_rect = [&](const rt_bvh_node& N) {
+        if (N.prim == RT_BVH_NONE) return false;
+        const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
+        return Pp.geom == RT_GEOM_RECT && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM);
+    };
+    auto exact_leaf = [&](const rt_bvh_node& N) { return N.prim != RT_BVH_NONE && ((N.prim & RT_BVH_EXACT) != 0 || plain_rect(N)); };
+    auto payload_slots = [&](const rt_bvh_node& N) { return plain_sphere(N) ? 1u : ((plain_box(N) || plain_rect(N)) ? 2u : (exact_leaf(N) ? 1u : 0u)); };
     // exact leaves keep their exact box in a payload slot; the box in the node itself, which only decides whether the walk
     // visits the leaf, is widened like every other node box (the fp32 slab test is accurate to ulps of origin / direction)
     double max_abs = 0.0;
@@ -726,6 +735,24 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
                 const double payload[4] = {c.x, c.y, c.z, sp.radius};
                 static_assert(sizeof(payload) == sizeof(WalkNode), "payload slot size");
                 std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
+            } else if (plain_rect(N)) {
+                // Shape::bound of a Rectangle (shape.rs:457-481): its extents, and the plane padded by 0.0001 on its axis
+                W.prim |= RT_BVH_EXACT | RT_NODE_PLAIN_RECT;
+                const rt_rect& R = D->rects[Pp.geom_index];
+                int p1, p2, oo; axis_perm(R.axis, p1, p2, oo);
+                double mn[3], mx[3];
+                mn[p1] = R.x0; mn[p2] = R.y0; mn[oo] = R.height - 0.0001;
+                mx[p1] = R.x1; mx[p2] = R.y1; mx[oo] = R.height + 0.0001;
+                float exact[8], rem[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                for (int c = 0; c < 3; ++c) { split_hi_lo(mn[c], exact[c], rem[c]); split_hi_lo(mx[c], exact[3 + c], rem[3 + c]); }
+                split_hi_lo(R.height, exact[6], exact[7]);
+                const uint32_t axis = R.axis;
+                std::memcpy(&rem[6], &axis, sizeof(axis));
+                std::memcpy(&nodes[new_index[i] + 1], exact, sizeof(exact));
+                std::memcpy(&nodes[new_index[i] + 2], rem, sizeof(rem));
+                auto down = [&](float x) { float f = (float)((double)x - pad); while ((double)f > (double)x - pad) f = std::nextafterf(f, -INFINITY); return f; };
+                auto up = [&](float x) { float f = (float)((double)x + pad); while ((double)f < (double)x + pad) f = std::nextafterf(f, INFINITY); return f; };
+                W.x0 = down(exact[0]); W.x1 = up(exact[3]); W.y0 = down(exact[1]); W.y1 = up(exact[4]); W.z0 = down(exact[2]); W.z1 = up(exact[5]);
             } else if (exact_leaf(N)) {
                 const float exact[8] = {N.min[0], N.min[1], N.min[2], N.max[0], N.max[1], N.max[2], 0.0f, 0.0f};
                 std::memcpy(&nodes[new_index[i] + 1], exact, sizeof(exact));
@@ -828,7 +855,7 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv_capped, float
     if (!(leaf & RT_BVH_EXACT)) return false;
     // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: (bound - origin) over the direction,
     // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
-    const bool plain = (leaf & RT_NODE_PLAIN_BOX) != 0;
+    const bool plain = (leaf & (RT_NODE_PLAIN_BOX | RT_NODE_PLAIN_RECT)) != 0;  // two payload slots: the second holds the remainders
     const float* exact = reinterpret_cast<const float*>(&S.bvh[w.leaf_node + 1]);
     const float* rem = reinterpret_cast<const float*>(&S.bvh[w.leaf_node + (plain ? 2u : 1u)]);  // the remainders; any slot when unused
     DevBox B;
@@ -845,6 +872,15 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv_capped, float
     enter = enter && !(hi <= lo);
     if (!enter) { RT_COUNT(leaves); return true; }
     if (!plain) return false;
+    if (leaf & RT_NODE_PLAIN_RECT) {  // Rectangle::intersect (shape.rs:309-332) from the leaf's own numbers
+        RT_COUNT(leaves); RT_COUNT(prim_tests);
+        uint32_t axis; memcpy(&axis, &rem[6], sizeof(axis));
+        int p1, p2, oo; axis_perm(axis, p1, p2, oo);
+        (void)oo;
+        float t;
+        if (rect_t<float, V3>(axis, exact[p1], exact[p2], exact[3 + p1], exact[3 + p2], exact[6], exact[7], r.o, r.d, tmin, w.tmax, t)) walk_accept(w, t, prim, 0);
+        return true;
+    }
     RT_COUNT(leaves); RT_COUNT(prim_tests);
     float t; int side;  // the leaf's box is the box: same arithmetic as box_t<float>, without fetching it
     if (box_sides_q(B, r.o, r.d, q, tmin, w.tmax, t, side)) walk_accept(w, t, prim, side);

@@ -70,16 +70,15 @@ def test_shape_intersect_parity_on_degenerate_rays(name, shape):
 
 def test_scene_closest_hit_parity_on_degenerate_rays(earth):
     """The same crafted rays through the BVH of every example scene (slab tests with zero, negative-zero and NaN direction
-    components: shape.rs:580-599), grid laid over the scene's finite extent.  In the two Cornell rooms the grid stands one
-    unit inside the walls: a ray that lies in the plane of a wall gets the plane parameter 0 / 0 there, which the
-    reference's rectangle accepts as a hit with t = NaN (shape.rs:321-329) unless the wall's own bounding-box test
-    (strict, in f64, shape.rs:593) turns the ray away first; the walk's leaf boxes are fp32 and visited on equality,
-    so that one case is not reproduced (the boxes' leaves are: their tests are exact)."""
+    components: shape.rs:580-599), grid laid over the scene's finite extent; in the Cornell rooms its outer planes are the
+    walls' planes, so many rays lie in the plane of a wall, where the rectangle's plane parameter is 0 / 0, accepted by
+    the reference as a hit with t = NaN (shape.rs:321-329) unless the wall's own bounding-box test turns the ray away first
+    (lib.rs:236-240): plain rectangles are exact leaves for that."""
     for name in EXAMPLES:
         sc, co = _example(name, earth)
         osc, oco = OracleScene.example(name, 1, earth if name == "final_scene" else None)
-        mn, mx = {"random_spheres": ((-11, 0, -11), (11, 1.2, 11)), "cornell": ((2, 2, 2), (553, 553, 553)), "perlin": ((-4, 0, -4), (5, 4, 4)),
-                  "cornell_smoke": ((2, 2, 2), (553, 553, 553)), "final_scene": ((-100, 0, 0), (560, 560, 560))}[name]
+        mn, mx = {"random_spheres": ((-11, 0, -11), (11, 1.2, 11)), "cornell": ((0, 0, 0), (555, 555, 555)), "perlin": ((-4, 0, -4), (5, 4, 4)),
+                  "cornell_smoke": ((0, 0, 0), (555, 555, 555)), "final_scene": ((-100, 0, 0), (560, 560, 560))}[name]
         o, d, t = degenerate_rays(mn, mx)
         ref = osc.intersect(o, d, t, seed=9)
         got = sc.intersect_batch(o, d, t, seed=9)

@@ -185,16 +185,15 @@ def test_shape_intersect_parity_on_degenerate_rays(name, shape):
 
 def test_scene_closest_hit_parity_on_degenerate_rays(earth):
     """The same crafted rays through the BVH of every example scene (slab tests with zero, negative-zero and NaN direction
-    components: shape.rs:580-599), grid laid over the scene's finite extent.  In the two Cornell rooms the grid stands one
-    unit inside the walls: a ray that lies in the plane of a wall gets the plane parameter 0 / 0 there, which the
-    reference's rectangle accepts as a hit with t = NaN (shape.rs:321-329) unless the wall's own bounding-box test
-    (strict, in f64, shape.rs:593) turns the ray away first; the walk's leaf boxes are fp32 and visited on equality,
-    so that one case is not reproduced (the boxes' leaves are: their tests are exact)."""
+    components: shape.rs:580-599), grid laid over the scene's finite extent; in the Cornell rooms its outer planes are the
+    walls' planes, so many rays lie in the plane of a wall, where the rectangle's plane parameter is 0 / 0, accepted by
+    the reference as a hit with t = NaN (shape.rs:321-329) unless the wall's own bounding-box test turns the ray away first
+    (lib.rs:236-240): plain rectangles are exact leaves for that."""
     for name in EXAMPLES:
         sc, co = _example(name, earth)
         osc, oco = OracleScene.example(name, 1, earth if name == "final_scene" else None)
-        mn, mx = {"random_spheres": ((-11, 0, -11), (11, 1.2, 11)), "cornell": ((2, 2, 2), (553, 553, 553)), "perlin": ((-4, 0, -4), (5, 4, 4)),
-                  "cornell_smoke": ((2, 2, 2), (553, 553, 553)), "final_scene": ((-100, 0, 0), (560, 560, 560))}[name]
+        mn, mx = {"random_spheres": ((-11, 0, -11), (11, 1.2, 11)), "cornell": ((0, 0, 0), (555, 555, 555)), "perlin": ((-4, 0, -4), (5, 4, 4)),
+                  "cornell_smoke": ((0, 0, 0), (555, 555, 555)), "final_scene": ((-100, 0, 0), (560, 560, 560))}[name]
         o, d, t = degenerate_rays(mn, mx)
         ref = osc.intersect(o, d, t, seed=9)
         got = twin_intersect(sc, o, d, t, seed=9)
@@ -347,7 +346,7 @@ def _walk_nodes(sc):
 def test_walk_node_array_keeps_the_reference_leaf_order(earth):
     """The node array the kernels walk (regrouped inner nodes, paired bounds, payload slots, sentinel): same leaves in the same
     order as the tree that crosses the ABI, nested subtrees, inner boxes containing everything below them, fewer nodes."""
-    PRIM_MASK, LEAF, PLAIN_BOX, PLAIN_SPHERE = 0x0FFFFFFF, 0x10000000, 0x40000000, 0x20000000
+    PRIM_MASK, PLAIN_RECT, LEAF, PLAIN_BOX, PLAIN_SPHERE = 0x07FFFFFF, 0x08000000, 0x10000000, 0x40000000, 0x20000000
     for name in EXAMPLES:
         sc, _ = _example(name, earth)
         d = sc.desc
@@ -387,6 +386,20 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
                         bx = d.boxes[P.geom_index]
                         full = ex.astype(np.float64) + raw[i + 2, :6].view(np.float32).astype(np.float64)   # value + remainder
                         assert np.allclose(full, list(bx.min) + list(bx.max), rtol=2e-14, atol=0)
+                    elif prim[i] & PLAIN_RECT:
+                        # a plain rectangle: its bound() (shape.rs:457-481) as value + remainder, the plane, the axis
+                        assert P.geom == _abi.RT_GEOM_RECT and P.xf_count == 0
+                        is_payload[i + 2] = True
+                        n_slots = 2
+                        rc = d.rects[P.geom_index]
+                        p1, p2, oo = [(1, 2, 0), (2, 0, 1), (0, 1, 2)][rc.axis]
+                        mn, mx = [0.0] * 3, [0.0] * 3
+                        mn[p1], mn[p2], mn[oo] = rc.x0, rc.y0, rc.height - 0.0001
+                        mx[p1], mx[p2], mx[oo] = rc.x1, rc.y1, rc.height + 0.0001
+                        full = ex.astype(np.float64) + raw[i + 2, :6].view(np.float32).astype(np.float64)
+                        assert np.allclose(full, mn + mx, rtol=2e-14, atol=0)
+                        h = raw[i + 1, 6:8].view(np.float32).astype(np.float64).sum()
+                        assert abs(h - rc.height) <= 2e-14 * max(1.0, abs(rc.height)) and raw[i + 2, 6] == rc.axis
                     assert skip[i] == i + 1 + n_slots
                     i += n_slots
                 else:
@@ -415,7 +428,7 @@ def test_wrapped_sphere_leaves_carry_the_centre_in_the_outer_frame():
     shape = rt.Shape.Sphere((3.0, 1.0, -2.0), 1.5).rotated(1, 30.0).translated((10.0, -4.0, 7.0)).rotated(0, -70.0)
     sc = rt.Scene([rt.Object(shape, rt.Material.Lambertian(rt.Texture.SolidColor((0.5, 0.5, 0.5))))], (0, 0, 0))
     raw = _walk_nodes(sc)
-    k = [i for i in range(len(raw) - 1) if raw[i, 7] >= 0x10000000 and (raw[i, 7] & 0x0FFFFFFF) == 0][0]
+    k = [i for i in range(len(raw) - 1) if raw[i, 7] >= 0x10000000 and (raw[i, 7] & 0x07FFFFFF) == 0][0]
     c = raw[k + 1].view(np.float64)
     p = np.array([3.0, 1.0, -2.0])
     a = np.radians(30.0); p = np.array([p[2] * np.sin(a) + p[0] * np.cos(a), p[1], p[2] * np.cos(a) - p[0] * np.sin(a)])   # rotate Y (geometry.rs:33-50)
