@@ -85,6 +85,30 @@ def test_scene_closest_hit_parity_on_degenerate_rays(earth):
         compare_hits(got, ref, name, allow_flag_mismatch=2e-2, allow_prim_mismatch=2e-2, allow_record_mismatch=2e-2, origins=o)
 
 
+def test_zero_and_negative_zero_direction_components():
+    """The hand-derived cases of tests/test_oracle.py (same name) through the C ABI: BoundingBox::hit's division by a zero
+    direction component, its `d < 0.0` swap that -0.0 escapes (shape.rs:580-599), Rectangle::intersect's NaN-blind
+    rejections (shape.rs:321-329)."""
+    S = rt.Shape
+    ball = rt.Scene([rt.Object(S.Sphere((0, 0, 0), 1.0), WHITE)], (0, 0, 0))
+    one = lambda sc, o, d, **kw: sc.intersect_batch([o], [d], [0.0], **kw)[0]
+    h = one(ball, [-5, 0, 0], [1, 0.0, 0.0])
+    assert h["hit"] == 1 and h["t"] == 4.0
+    assert one(ball, [-5, 2, 0], [1, 0.0, 0.0])["hit"] == 0
+    assert one(ball, [-5, 0, 0], [1, -0.0, 0.0], scope=0)["hit"] == 1      # the sphere alone: no bounding-box test
+    assert one(ball, [-5, 0, 0], [1, -0.0, 0.0])["hit"] == 0               # behind its bounding box: missed
+    wall = rt.Scene([rt.Object(S.rectangle((0, 0, 1), (2, 2, 1)), WHITE)], (0, 0, 0))
+    for scope in (0, -1):                                                  # the rectangle alone, and behind its leaf's box
+        h = one(wall, [-1, 1, 1], [1, 0, 0.0], scope=scope)
+        assert h["hit"] == 1 and np.isnan(h["t"]) and np.isnan(h["point"]).all() and list(h["normal"]) == [0, 0, 1]
+        assert one(wall, [-1, 1, 2], [1, 0, 0.0], scope=scope)["hit"] == 0
+        assert one(wall, [-1, 1, 0], [1, 0, 0.0], scope=scope)["hit"] == 0
+    z = one(wall, [1, 1, 0], [0.0, 0.0, 0.0], scope=0)
+    assert z["hit"] == 1 and z["t"] == INF and np.isnan(z["point"]).all()
+    assert one(wall, [1, 1, 0], [0.0, 0.0, 0.0], scope=0, tmax=1e30)["hit"] == 0
+    assert one(wall, [-1, 1, 1], [0.0, 0.0, 0.0])["hit"] == 0
+
+
 def test_empty_and_ragged_batches():
     sc = rt.Scene([rt.Object(rt.Shape.Sphere((0, 0, 0), 1.0), WHITE)], (0, 0, 0))
     assert len(sc.intersect_batch(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))) == 0

@@ -174,6 +174,46 @@ def test_constant_medium_quirks():
     assert from_inside["hit"] == 0   # both boundary queries resolve behind the origin: no second scattering
 
 
+def test_zero_and_negative_zero_direction_components():
+    """Hand-derived from the reference's arithmetic.  BoundingBox::hit (shape.rs:580-599) divides by the direction
+    component and swaps the quotients only for d < 0.0; Rectangle::intersect (shape.rs:321-329) rejects with
+    `t < tmin || t > tmax` and `p < x0 || p > x1 ...`, all of which are false for NaN."""
+    S = rt.Shape
+    white = rt.Material.Lambertian(rt.Texture.SolidColor((1, 1, 1)))
+    ball = S.Sphere((0, 0, 0), 1.0)
+    scene = OracleScene([rt.Object(ball, white)], (0, 0, 0))
+    alone = OracleShape(ball)
+    # d.y = d.z = +0.0: the y and z quotients are (-1 - 0) / 0 = -inf and (1 - 0) / 0 = +inf, the slab is open: hit at t = 4
+    o, t0 = [[-5, 0, 0]], [0.0]
+    assert scene.intersect(o, [[1, 0.0, 0.0]], t0, seed=1)[0]["hit"] == 1 and scene.intersect(o, [[1, 0.0, 0.0]], t0, seed=1)[0]["t"] == 4.0
+    # the same ray passing beside the box (y = 2): both y quotients are -inf, tmax = -inf <= tmin: the box is missed
+    assert scene.intersect([[-5, 2, 0]], [[1, 0.0, 0.0]], t0, seed=1)[0]["hit"] == 0
+    # d.y = -0.0 is not "< 0.0", so the quotients +inf, -inf stay in that order: tmin = +inf, tmax = -inf, the box is
+    # missed although the sphere itself (no bounding-box test in Shape::intersect) is hit
+    assert alone.intersect(o, [[1, -0.0, 0.0]], t0, 0.001, INF)[0]["hit"] == 1
+    assert scene.intersect(o, [[1, -0.0, 0.0]], t0, seed=1)[0]["hit"] == 0
+    # a ray in the plane of a rectangle: t = (1 - 1) / 0 = NaN passes every rejection, the hit has t = NaN and a NaN point
+    wall = OracleShape(S.rectangle((0, 0, 1), (2, 2, 1)))
+    h = wall.intersect([[-1, 1, 1]], [[1, 0, 0.0]], t0, 0.001, INF)[0]
+    assert h["hit"] == 1 and np.isnan(h["t"]) and np.isnan(h["point"]).all() and list(h["normal"]) == [0, 0, 1]
+    # parallel to the rectangle but off its plane: t = -1 / 0 = -inf < tmin: no hit; from the other side t = +inf passes
+    # `t > tmax` only because tmax is +inf, then the point origin + direction * inf = (inf, NaN, NaN) fails `p1 > x1`
+    assert wall.intersect([[-1, 1, 2]], [[1, 0, 0.0]], t0, 0.001, INF)[0]["hit"] == 0
+    assert wall.intersect([[-1, 1, 0]], [[1, 0, 0.0]], t0, 0.001, INF)[0]["hit"] == 0
+    # the zero direction at a point inside the rectangle's extents: t = +inf passes, the point is NaN in every component
+    # (0 * inf), which passes the extents test: a hit at t = inf -- but only while tmax is +inf
+    z = wall.intersect([[1, 1, 0]], [[0.0, 0.0, 0.0]], t0, 0.001, INF)[0]
+    assert z["hit"] == 1 and z["t"] == INF and np.isnan(z["point"]).all()
+    assert wall.intersect([[1, 1, 0]], [[0.0, 0.0, 0.0]], t0, 0.001, 1e30)[0]["hit"] == 0
+    # in a scene the wall's bounding box (z in 1 -+ 0.0001, shape.rs:457-481) comes first: for the in-plane ray from
+    # x = -1 its x quotients are 1 and 3, y and z are open, so the box is entered and the NaN hit stands ...
+    room = OracleScene([rt.Object(S.rectangle((0, 0, 1), (2, 2, 1)), white)], (0, 0, 0))
+    r = room.intersect([[-1, 1, 1]], [[1, 0, 0.0]], t0, seed=1)[0]
+    assert r["hit"] == 1 and np.isnan(r["t"])
+    # ... while the zero direction outside the box on x (quotients +inf, +inf: tmax <= tmin) never reaches the wall
+    assert room.intersect([[-1, 1, 1]], [[0.0, 0.0, 0.0]], t0, seed=1)[0]["hit"] == 0
+
+
 def test_moving_sphere():
     s = OracleShape(rt.Shape.sphere(1.0, (0.0, (0, 0, 0)), (1.0, (4, 0, 0))))
     h0 = s.intersect([[0, 0, -5]], [[0, 0, 1]], [0.0], 0.001, INF)[0]
