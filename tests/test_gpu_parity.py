@@ -109,6 +109,48 @@ def test_zero_and_negative_zero_direction_components():
     assert one(wall, [-1, 1, 1], [0.0, 0.0, 0.0])["hit"] == 0
 
 
+def _gpu_scatter(shape, material, o, d, seed=5, key=(3, 1, 0)):
+    sc = rt.Scene([rt.Object(shape, material)], (0, 0, 0))
+    h = sc.intersect_batch([o], [d], [0.0], seed=seed)
+    assert h[0]["hit"] == 1
+    s = sc.scatter_batch(h, seed=seed, keys=[key])[0]
+    return h[0], int(s["scattered"]), s["color"].astype(np.float64), s["origin"].astype(np.float64), s["direction"].astype(np.float64)
+
+
+def test_material_rules_by_hand():
+    """The hand-derived cases of tests/test_oracle.py (same name) through rt_intersect_batch + rt_scatter_batch:
+    Material::scatter (materials.rs:28-113) where the outcome does not hang on a random draw, or only within bounds.
+    fp32 tolerances: 1e-6."""
+    S, M, T = rt.Shape, rt.Material, rt.Texture
+    floor = S.rectangle((-5, 0, -5), (5, 0, 5))
+    down, up = [1.0, -1.0, 0.0], [1.0, 1.0, 0.0]
+    r2 = np.sqrt(0.5)
+    for o, d in (([-2, 2, 0], down), ([-2, -2, 0], up)):
+        _, sc, col, _, _ = _gpu_scatter(floor, M.DiffuseLight(T.SolidColor((15, 7, 4))), o, d)
+        assert sc == 0 and list(col) == [15, 7, 4]
+    _, sc, col, ro, rd = _gpu_scatter(floor, M.Metal((0.8, 0.6, 0.2), 0.0), [-2, 2, 0], down)
+    assert sc == 1 and np.allclose(col, [0.8, 0.6, 0.2], rtol=1e-7) and np.allclose(ro, [0, 0, 0], atol=1e-6) and np.allclose(rd, [r2, r2, 0], atol=1e-6)
+    _, sc, col, _, _ = _gpu_scatter(floor, M.Metal((0.8, 0.6, 0.2), 0.0), [-2, -2, 0], up)
+    assert sc == 0 and list(col) == [0, 0, 0]
+    _, sc, col, ro, rd = _gpu_scatter(floor, M.glass(), [-2, -2, 0], up)
+    assert sc == 1 and list(col) == [1, 1, 1] and np.allclose(rd, [r2, -r2, 0], atol=1e-6)
+    for sample in range(8):
+        _, sc, col, ro, rd = _gpu_scatter(floor, M.glass(), [0, 3, 0], [0.0, -2.0, 0.0], key=(3, sample, 0))
+        assert sc == 1 and rd[0] == 0 and rd[2] == 0 and abs(abs(rd[1]) - 1.0) < 1e-6
+    for sample in range(8):
+        _, sc, col, ro, rd = _gpu_scatter(floor, M.Lambertian(T.SolidColor((0.2, 0.4, 0.6))), [-2, 2, 0], down, key=(9, sample, 2))
+        assert sc == 1 and abs(np.linalg.norm(rd - [0, 1, 0]) - 1.0) < 1e-6 and rd[1] > 0 and np.allclose(col, [0.2, 0.4, 0.6], rtol=1e-7)
+    _, sc, col, ro, rd = _gpu_scatter(floor, M.Lambertian(T.SolidColor((0.2, 0.4, 0.6))), [-2, -2, 0], up)
+    assert sc == 1 and rd[1] > 0 and np.allclose(col, [0.2, 0.4, 0.6], rtol=1e-7)
+    _, sc, col, ro, rd = _gpu_scatter(floor, M.Isotropic(T.SolidColor((0.5, 0.5, 0.5))), [-2, 2, 0], down)
+    assert sc == 1 and abs(np.linalg.norm(rd) - 1.0) < 1e-6 and list(col) == [0.5, 0.5, 0.5] and np.allclose(ro, [0, 0, 0], atol=1e-6)
+    chk = M.DiffuseLight(T.Checkered(T.SolidColor((1, 0, 0)), T.SolidColor((0, 1, 0))))
+    wall = S.rectangle((0, 0, 0.1), (1, 1, 0.1))
+    for (x, y), want in (((0.1, 0.1), [0, 1, 0]), ((0.4, 0.1), [1, 0, 0])):
+        _, sc, col, _, _ = _gpu_scatter(wall, chk, [x, y, -1], [0.0, 0.0, 1.0])
+        assert sc == 0 and list(col) == want
+
+
 def test_empty_and_ragged_batches():
     sc = rt.Scene([rt.Object(rt.Shape.Sphere((0, 0, 0), 1.0), WHITE)], (0, 0, 0))
     assert len(sc.intersect_batch(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))) == 0

@@ -214,6 +214,60 @@ def test_zero_and_negative_zero_direction_components():
     assert room.intersect([[-1, 1, 1]], [[0.0, 0.0, 0.0]], t0, seed=1)[0]["hit"] == 0
 
 
+def _oracle_scatter(shape, material, o, d, seed=5, key=(3, 1, 0)):
+    """One ray against a one-object scene, then Material::scatter on the hit: (hit record, scattered?, colour, origin, direction)."""
+    sc = OracleScene([rt.Object(shape, material)], (0, 0, 0))
+    h = sc.intersect([o], [d], [0.0], seed=seed)
+    assert h[0]["hit"] == 1
+    flag, col, ro, rd = C.c_int32(), (C.c_double * 3)(), (C.c_double * 3)(), (C.c_double * 3)()
+    oracle().orc_scene_scatter(sc.h, h.ctypes.data, seed, key[0], key[1], key[2], C.byref(flag), col, ro, rd)
+    return h[0], flag.value, np.array(col), np.array(ro), np.array(rd)
+
+
+def test_material_rules_by_hand():
+    """Material::scatter (materials.rs:28-113) where the outcome does not hang on a random draw, or only within bounds."""
+    S, M, T = rt.Shape, rt.Material, rt.Texture
+    floor = S.rectangle((-5, 0, -5), (5, 0, 5))           # Axis::Y, normal (0, 1, 0) whatever the side hit (shape.rs:330)
+    down = [1.0, -1.0, 0.0]
+    r2 = np.sqrt(0.5)
+    # DiffuseLight: Emitted(colour), from either face (materials.rs:95-99)
+    for o, d in (([-2, 2, 0], down), ([-2, -2, 0], [1.0, 1.0, 0.0])):
+        h, sc, col, _, _ = _oracle_scatter(floor, M.DiffuseLight(T.SolidColor((15, 7, 4))), o, d)
+        assert sc == 0 and list(col) == [15, 7, 4]
+    # Metal without fuzz: the mirror direction of the unit in_vec, attenuation = albedo (materials.rs:49-63, :132-134)
+    h, sc, col, ro, rd = _oracle_scatter(floor, M.Metal((0.8, 0.6, 0.2), 0.0), [-2, 2, 0], down)
+    assert sc == 1 and list(col) == [0.8, 0.6, 0.2] and np.allclose(ro, [0, 0, 0], atol=1e-15) and np.allclose(rd, [r2, r2, 0], atol=1e-15)
+    # ... and from below the reflected ray points against the (never flipped) normal: scattered . normal < 0 -> Emitted(black)
+    h, sc, col, _, _ = _oracle_scatter(floor, M.Metal((0.8, 0.6, 0.2), 0.0), [-2, -2, 0], [1.0, 1.0, 0.0])
+    assert sc == 0 and list(col) == [0, 0, 0]
+    # Dielectric from the back face (in_vec . normal > 0): eta = ri = 1.5, cos_theta = -min(in . n, 1) = -sqrt(1/2),
+    # sin_theta = sqrt(1/2), eta * sin_theta = 1.06 > 1: reflected without a draw (materials.rs:65-93)
+    h, sc, col, ro, rd = _oracle_scatter(floor, M.glass(), [-2, -2, 0], [1.0, 1.0, 0.0])
+    assert sc == 1 and list(col) == [1, 1, 1] and np.allclose(rd, [r2, -r2, 0], atol=1e-15)
+    # Dielectric head-on from the front: eta = 1/1.5, cos_theta = 1, schlick = r0 = 0.04; either branch keeps the ray on
+    # the axis: reflect -> (0, 1, 0), refract -> (in + n cos) eta - n sqrt(1 - 0) = (0, -1, 0)
+    for sample in range(8):
+        h, sc, col, ro, rd = _oracle_scatter(floor, M.glass(), [0, 3, 0], [0.0, -2.0, 0.0], key=(3, sample, 0))
+        assert sc == 1 and rd[0] == 0 and rd[2] == 0 and abs(abs(rd[1]) - 1.0) < 1e-15
+    # Lambertian: direction = unit vector + normal, not normalised; attenuation = colour for cos > 0 (materials.rs:30-47)
+    for sample in range(8):
+        h, sc, col, ro, rd = _oracle_scatter(floor, M.Lambertian(T.SolidColor((0.2, 0.4, 0.6))), [-2, 2, 0], down, key=(9, sample, 2))
+        assert sc == 1 and abs(np.linalg.norm(rd - [0, 1, 0]) - 1.0) < 1e-12 and rd[1] > 0 and np.allclose(col, [0.2, 0.4, 0.6], rtol=1e-15)
+    # ... and under the floor the same direction lies on the far side of the surface the ray came to (the normal is not
+    # turned), still cos > 0 against that normal: the colour is kept and the path goes through the surface
+    h, sc, col, ro, rd = _oracle_scatter(floor, M.Lambertian(T.SolidColor((0.2, 0.4, 0.6))), [-2, -2, 0], [1.0, 1.0, 0.0])
+    assert sc == 1 and rd[1] > 0 and np.allclose(col, [0.2, 0.4, 0.6], rtol=1e-15)
+    # Isotropic: a unit direction from the hit point, attenuation = colour (materials.rs:101-112)
+    h, sc, col, ro, rd = _oracle_scatter(floor, M.Isotropic(T.SolidColor((0.5, 0.5, 0.5))), [-2, 2, 0], down)
+    assert sc == 1 and abs(np.linalg.norm(rd) - 1.0) < 1e-12 and list(col) == [0.5, 0.5, 0.5] and np.allclose(ro, [0, 0, 0], atol=1e-15)
+    # Checkered on the world-space point (textures.rs:48-55): sin(10x) sin(10y) sin(10z) < 0 -> odd
+    chk = M.DiffuseLight(T.Checkered(T.SolidColor((1, 0, 0)), T.SolidColor((0, 1, 0))))
+    wall = S.rectangle((0, 0, 0.1), (1, 1, 0.1))           # z = 0.1: sin(1) > 0
+    for (x, y), want in (((0.1, 0.1), [0, 1, 0]), ((0.4, 0.1), [1, 0, 0])):   # sin(1) sin(1) > 0 -> even; sin(4) < 0 -> odd
+        h, sc, col, _, _ = _oracle_scatter(wall, chk, [x, y, -1], [0.0, 0.0, 1.0])
+        assert sc == 0 and list(col) == want
+
+
 def test_moving_sphere():
     s = OracleShape(rt.Shape.sphere(1.0, (0.0, (0, 0, 0)), (1.0, (4, 0, 0))))
     h0 = s.intersect([[0, 0, -5]], [[0, 0, 1]], [0.0], 0.001, INF)[0]
