@@ -120,6 +120,35 @@ def test_flattened_examples(earth):
                 assert all(n.min[c] <= d.bvh[j].min[c] and n.max[c] >= d.bvh[j].max[c] for c in range(3))
 
 
+def test_camera_frame_by_hand():
+    """Camera::new (lib.rs:347-384) on numbers worked out by hand: vfov 90 degrees (h = tan 45 = 1), aspect 2, focus 3, looking
+    down -z from (1, 2, 3) with vup = +y: w = (0, 0, 1), u = vup x w = (1, 0, 0), v = w x u = (0, 1, 0); the viewport is
+    2h * aspect = 4 wide and 2h = 2 high, times the focus distance; aperture 0.5 -> lens radius 0.25.  Rays (lib.rs:55-60,
+    :389-401): direction = lower_left + horizontal * (i + U) / (w - 1) + vertical * (j + U) / (h - 1) - origin - lens offset."""
+    co = rt.CameraOptions(aperture=0.5, aspect_ratio=2.0, focus_distance=3.0, looking_at=(1, 2, -7), origin=(1, 2, 3), shutter_close=2.0, shutter_open=1.0,
+                          vfov=90.0, vup=(0, 1, 0))
+    cam = rt.Camera(co)
+    a = cam.abi
+    assert np.allclose(list(a.horizontal), [12, 0, 0], atol=1e-12) and np.allclose(list(a.vertical), [0, 6, 0], atol=1e-12)
+    assert np.allclose(list(a.lower_left_corner), [1 - 6, 2 - 3, 3 - 3], atol=1e-12) and list(a.origin) == [1, 2, 3]
+    assert np.allclose(list(a.u), [1, 0, 0], atol=1e-15) and np.allclose(list(a.v), [0, 1, 0], atol=1e-15) and a.lens_radius == 0.25
+    w, h, n = 5, 3, 400
+    rng = np.random.default_rng(1)
+    pi, pj, ss = rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, 50, n)
+    for o, d, t in (oracle_camera_rays(co.to_c(), w, h, 77, pi, pj, ss),):
+        off = o - [1, 2, 3]                                           # the lens offset: inside the disc of radius 0.25 in the u-v plane
+        assert (np.hypot(off[:, 0], off[:, 1]) < 0.25).all() and (off[:, 2] == 0).all() and np.hypot(off[:, 0], off[:, 1]).max() > 0.2
+        target = o + d                                                # origin' + direction = the point on the focus plane
+        s = (target[:, 0] - (-5)) / 12 * (w - 1) - pi                 # = U1 in [0, 1)
+        v = (target[:, 1] - (-1)) / 6 * (h - 1) - pj
+        assert (s > -1e-9).all() and (s < 1 + 1e-9).all() and (v > -1e-9).all() and (v < 1 + 1e-9).all() and np.allclose(target[:, 2], 0.0, atol=1e-12)
+        assert (t >= 1.0).all() and (t < 2.0).all() and t.std() > 0.2  # random_time: uniform in [shutter_open, shutter_close)
+    out = np.zeros((n, 7), np.float32)
+    pi32, pj32, ss32 = (x.astype(np.uint32) for x in (pi, pj, ss))
+    twin().twin_camera_rays(C.byref(a), w, h, 77, n, pi32.ctypes.data, pj32.ctypes.data, ss32.ctypes.data, out.ctypes.data)
+    assert np.array_equal(out[:, 0:3], o.astype(np.float32)) and np.abs(out[:, 3:6] - d).max() < 1e-6
+
+
 def test_camera_frame_matches_the_oracle(earth):
     for name in EXAMPLES:
         _, co = _example(name, earth)
