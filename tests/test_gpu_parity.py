@@ -150,6 +150,14 @@ def test_material_rules_by_hand():
         _, sc, col, _, _ = _gpu_scatter(wall, chk, [x, y, -1], [0.0, 0.0, 1.0])
         assert sc == 0 and list(col) == want
 
+    # Image (textures.rs:59-76): u clamped, v flipped and clamped, texel (min(u W, W-1), min((1 - v) H, H-1)), value / 255;
+    # on an Axis::Z rectangle u = (x - x0) / (x1 - x0), v = (y - y0) / (y1 - y0) (shape.rs:323-324)
+    img = np.arange(4 * 2 * 3, dtype=np.uint8).reshape(2, 4, 3) * 10          # rows = j (top row first), columns = i
+    card = S.rectangle((0, 0, 0), (4, 2, 0))
+    for (x, y), (i, j) in (((0.5, 1.9), (0, 0)), ((3.5, 1.9), (3, 0)), ((1.5, 0.5), (1, 1)), ((4.0, 0.0), (3, 1)), ((2.0, 1.0), (2, 1))):
+        h, sc, col, _, _ = _gpu_scatter(card, M.DiffuseLight(T.Image(img)), [x, y, -1], [0.0, 0.0, 1.0])
+        assert sc == 0 and np.allclose(col, img[j, i] / 255.0, rtol=1e-6), (x, y)
+
 
 def test_empty_and_ragged_batches():
     sc = rt.Scene([rt.Object(rt.Shape.Sphere((0, 0, 0), 1.0), WHITE)], (0, 0, 0))
