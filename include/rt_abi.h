@@ -163,7 +163,7 @@ typedef struct rt_bvh_node {
 
 typedef struct rt_scene_desc {
     uint32_t abi_version; /* RT_ABI_VERSION */
-    /* n_prims: at least 1 (Scene::new asserts a non-empty object list, src/lib.rs:161) and below 2^26 */
+    /* n_prims: at least 1 (Scene::new asserts a non-empty object list, src/lib.rs:161) and below 2^21 */
     uint32_t n_prims, n_spheres, n_rects, n_boxes, n_xforms, n_materials, n_textures, n_images, n_perm_tables, n_bvh_nodes;
     uint32_t reserved0;
     const rt_prim* prims;

@@ -536,8 +536,14 @@ struct Ray {
 #define RT_NODE_PLAIN_BOX 0x40000000u
 #define RT_NODE_PLAIN_SPHERE 0x20000000u
 
-struct WalkNode { float x0, x1, y0, y1, z0, z1; uint32_t skip, prim; };
+struct alignas(16) WalkNode { float x0, x1, y0, y1, z0, z1; uint32_t skip, prim; };
 static_assert(sizeof(WalkNode) == 32, "node slot size");
+// Positions in the node array -- the links in the nodes, the walk's place, the noted leaves -- are byte offsets
+// (slot number * 32): a read from the array then needs no address arithmetic beyond its base.
+#define RT_NODE_STRIDE 32u
+RT_HD const WalkNode& node_at(const WalkNode* base, uint32_t offset) {  // (the array and every position in it are at least 16-byte aligned)
+    return *static_cast<const WalkNode*>(__builtin_assume_aligned(reinterpret_cast<const char*>(base) + offset, 16));
+}
 
 // (host side) The inner nodes over the leaf sequence are regrouped.  The walk tests every child of a node it enters, so
 // the expected number of box tests is the sum over all nodes of P(ray meets the parent's box), about
@@ -716,10 +722,10 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
     uint32_t at = 0;
     for (uint32_t i = 0; i < n_in; ++i) { new_index[i] = at; at += 1u + payload_slots(tree[i]); }
     new_index[n_in] = at;
-    nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at, at});
+    nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at * RT_NODE_STRIDE, at * RT_NODE_STRIDE});
     for (uint32_t i = 0; i < n_in; ++i) {
         const rt_bvh_node& N = tree[i];
-        WalkNode W{N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2], new_index[N.skip], new_index[i] + 1u};
+        WalkNode W{N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2], new_index[N.skip] * RT_NODE_STRIDE, (new_index[i] + 1u) * RT_NODE_STRIDE};
         if (N.prim != RT_BVH_NONE) {
             W.prim = RT_NODE_LEAF | (N.prim & RT_BVH_EXACT) | (N.prim & RT_NODE_PRIM_MASK);
             const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
@@ -773,8 +779,8 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
 }
 
 struct Walk {
-    uint32_t i;     // next node to look at
-    uint32_t leaf_node;  // index of the node the last walk_step stood on
+    uint32_t i;     // next node to look at (byte offset in the node array, like every node position)
+    uint32_t leaf_node;  // the node the last walk_step stood on
     float tmax;     // shrinking upper end of the ray interval
     float t;        // accepted hit so far
     uint32_t prim;
@@ -800,9 +806,9 @@ RT_HD bool node_hit(const WalkNode& N, V3 inv, V3 oi, float tmin, float tmax) {
 }
 
 // One node step.  Returns the leaf's prim field when the ray now stands on a leaf whose primitive has to be
-// tried (w.i already points past it), RT_BVH_NONE otherwise.  Requires w.i < S.n_bvh_nodes.
+// tried (w.i already points past it), RT_BVH_NONE otherwise.  Requires w.i to be before the sentinel.
 RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w) {
-    const WalkNode N = S.bvh[w.i];
+    const WalkNode N = node_at(S.bvh, w.i);
     RT_COUNT(nodes);
     if (!node_hit(N, inv, oi, tmin, fminf(w.tmax, RT_WALK_FAR))) { w.i = N.skip; return RT_BVH_NONE; }
     w.leaf_node = w.i;
@@ -815,13 +821,19 @@ RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w)
 // That changes no result: the tests still run in leaf order against the bound as it is then, a walk that goes on with a
 // bound not yet lowered only visits nodes it might have skipped, and a leaf reached that way fails its test (its
 // primitive lies inside its box, beyond the bound; exact leaves repeat their box test when they are tried).
-// A walk with two leaves pending, or one that has left the tree (w.i == S.n_bvh_nodes, the sentinel slot), stays as it is.
+// A walk with two leaves pending, or one that has left the tree (w.i on the sentinel slot), stays as it is.
 #if defined(__HIPCC__)
 // m0 / m1: the lanes of the wave whose p0 / p1 hold a leaf (p0 != RT_BVH_NONE, p1 != RT_BVH_NONE), kept as wave masks by
 // the caller over a run of steps.  All of a step's conditions are formed as wave masks from its two comparisons
 // (mask arithmetic runs on the scalar unit), so a step spends its vector instructions on the slab test and four selects.
+// LDS_AT_ZERO: the node array stands in LDS from address 0 on, so a node's position is its address (the caller has checked
+// that the kernel has no LDS of its own in front of the dynamic array).
+template <bool LDS_AT_ZERO>
 __device__ __forceinline__ void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& p0, uint32_t& p1, unsigned long long& m0, unsigned long long& m1) {
-    const WalkNode N = S.bvh[w.i];
+    typedef __attribute__((address_space(3))) const WalkNode* LdsNode;
+    WalkNode N;
+    if (LDS_AT_ZERO) { const LdsNode at = reinterpret_cast<LdsNode>((size_t)w.i); N.x0 = at->x0; N.x1 = at->x1; N.y0 = at->y0; N.y1 = at->y1; N.z0 = at->z0; N.z1 = at->z1; N.skip = at->skip; N.prim = at->prim; }
+    else N = node_at(S.bvh, w.i);
     const F2 x = fma2(N.x0, N.x1, inv.x, -oi.x), y = fma2(N.y0, N.y1, inv.y, -oi.y), z = fma2(N.z0, N.z1, inv.z, -oi.z);
     const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), tmin));
     const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), w.tmax));
@@ -845,7 +857,7 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv_capped, float
     const uint32_t prim = leaf & RT_NODE_PRIM_MASK;
     if (leaf & RT_NODE_PLAIN_SPHERE) {
         RT_COUNT(leaves); RT_COUNT(prim_tests);
-        const double* c = reinterpret_cast<const double*>(&S.bvh[w.leaf_node + 1]);
+        const double* c = reinterpret_cast<const double*>(&node_at(S.bvh, w.leaf_node + RT_NODE_STRIDE));
         rt_sphere sp;
         sp.center[0] = c[0]; sp.center[1] = c[1]; sp.center[2] = c[2]; sp.radius = c[3];
         double t64;
@@ -856,8 +868,8 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv_capped, float
     // BoundingBox::hit (shape.rs:580-599) on the primitive's own box: (bound - origin) over the direction,
     // swap for negative directions, NaN-ignoring min/max, miss when tmax <= tmin.
     const bool plain = (leaf & (RT_NODE_PLAIN_BOX | RT_NODE_PLAIN_RECT)) != 0;  // two payload slots: the second holds the remainders
-    const float* exact = reinterpret_cast<const float*>(&S.bvh[w.leaf_node + 1]);
-    const float* rem = reinterpret_cast<const float*>(&S.bvh[w.leaf_node + (plain ? 2u : 1u)]);  // the remainders; any slot when unused
+    const float* exact = reinterpret_cast<const float*>(&node_at(S.bvh, w.leaf_node + RT_NODE_STRIDE));
+    const float* rem = reinterpret_cast<const float*>(&node_at(S.bvh, w.leaf_node + (plain ? 2u : 1u) * RT_NODE_STRIDE));  // the remainders; any slot when unused
     DevBox B;
     for (int c = 0; c < 3; ++c) { B.min[c] = exact[c]; B.max[c] = exact[3 + c]; B.min_lo[c] = plain ? rem[c] : 0.0f; B.max_lo[c] = plain ? rem[3 + c] : 0.0f; }
     float q[6];
@@ -902,7 +914,7 @@ RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax,
     const V3 inv_c = walk_cap(ray_inv(r.d));
     const V3 oi = v3(r.o.x * inv_c.x, r.o.y * inv_c.y, r.o.z * inv_c.z);
     Walk w; walk_init(w, tmax);
-    const uint32_t n = S.n_bvh_nodes;
+    const uint32_t n = S.n_bvh_nodes * RT_NODE_STRIDE;
     for (;;) {
         uint32_t leaf = RT_BVH_NONE;
         while (w.i < n && leaf == RT_BVH_NONE) leaf = walk_step(S, inv_c, oi, tmin, w);

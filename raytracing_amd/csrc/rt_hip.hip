@@ -149,11 +149,13 @@ template <bool NODES_IN_LDS>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LDS ? 6 : 1) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
                                                                                    uint2* hits, uint32_t bounce) {
     extern __shared__ uint4 lds_nodes[];
-    __shared__ uint32_t next_ray;
+    // (the workgroup's ray counter stands behind the node array, so that the array starts at LDS address 0 and a node's
+    // byte offset is its address)
+    uint32_t& next_ray = *reinterpret_cast<uint32_t*>(lds_nodes + (NODES_IN_LDS ? 2u * (S0.n_bvh_nodes + 1u) : 0u));
     const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_nodes = S.n_bvh_nodes;
+    const uint32_t n_nodes = S.n_bvh_nodes * RT_NODE_STRIDE;  // the sentinel's position: node positions are byte offsets
     const float tmin = 0.001f;  // lib.rs:90: (0.001, inf)
     // The queue is dealt out to the workgroups in groups of RT_TRAV_GROUP rays, round robin, so that every workgroup
     // gets an even sample of the queue whatever order it is in; inside a workgroup the waves draw from the workgroup's
@@ -218,12 +220,12 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             Walk w; w.i = node; w.tmax = fminf(t_end, RT_WALK_FAR);
             unsigned long long m0 = __ballot(p0 != RT_BVH_NONE), m1 = ~__ballot(p1 == RT_BVH_NONE);
 #pragma unroll
-            for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat(S, inv, oi, tmin, w, p0, p1, m0, m1);
+            for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat<NODES_IN_LDS>(S, inv, oi, tmin, w, p0, p1, m0, m1);
             node = w.i;
         } else {
 #ifdef RT_TRAV_STATS
             {
-                const uint32_t lf = (active && p0 != RT_BVH_NONE) ? S.bvh[p0].prim : 0u;
+                const uint32_t lf = (active && p0 != RT_BVH_NONE) ? node_at(S.bvh, p0).prim : 0u;
                 const uint32_t ns = (uint32_t)__popcll(__ballot((lf & RT_NODE_PLAIN_SPHERE) != 0)), nb = (uint32_t)__popcll(__ballot((lf & RT_NODE_PLAIN_BOX) != 0));
                 const uint32_t np = (uint32_t)__popcll(pending);
                 RT_STAT(2, 1); RT_STAT(3, np); RT_STAT(4, ns); RT_STAT(5, nb); RT_STAT(6, np - ns - nb);
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
                 const bool has = active && p0 != RT_BVH_NONE;
-                const uint32_t leaf = has ? S.bvh[p0].prim : 0u;
+                const uint32_t leaf = has ? node_at(S.bvh, p0).prim : 0u;
 #ifdef RT_TRAV_STATS
                 { const uint32_t served = (uint32_t)__popcll(__ballot(has && ((leaf & RT_NODE_PLAIN_SPHERE) != 0u) == (round == 0))); RT_STAT(10 + round, served); }
 #endif
@@ -488,7 +490,7 @@ static rt_status validate_desc(const rt_scene_desc* D) {
     if (!D) return fail(RT_ERR_INVALID_ARGUMENT, "scene description is null");
     if (D->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "abi_version mismatch");
     if (D->n_prims == 0) return fail(RT_ERR_EMPTY_SCENE, "a scene needs at least one object (Scene::new asserts this)");
-    if (D->n_prims >= (1u << 26)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");  // (node indices stay below RT_NODE_LEAF)
+    if (D->n_prims >= (1u << 21)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");  // (node positions, in bytes, stay below RT_NODE_LEAF)
     if (!D->prims || !D->materials || D->n_materials == 0) return fail(RT_ERR_INVALID_ARGUMENT, "prims / materials missing");
     if ((D->n_spheres && !D->spheres) || (D->n_rects && !D->rects) || (D->n_boxes && !D->boxes) || (D->n_xforms && !D->xforms) ||
         (D->n_textures && !D->textures) || (D->n_images && !D->images) || (D->n_perm_tables && !D->perm_tables) || (D->n_bvh_nodes && !D->bvh))
@@ -771,6 +773,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const size_t node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
     const bool nodes_in_lds = sc->view.n_bvh_nodes > 0 && node_bytes <= 144u * 1024u && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
     if (nodes_in_lds && !sc->lds_attr_set) {
+        hipFuncAttributes fa;  // k_traverse takes the start of its dynamic LDS for address 0 (walk_step_flat)
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_traverse<true>)));
+        if (fa.sharedSizeBytes != 0) return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array");
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         sc->lds_attr_set = true;
@@ -801,9 +806,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     };
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
-            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes + 16, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
         else
-            hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+            hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), 16, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
     };
     auto launch_tail = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)

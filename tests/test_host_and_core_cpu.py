@@ -381,8 +381,11 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
         d = sc.desc
         raw = _walk_nodes(sc)
         f = raw[:, :6].view(np.float32)
-        skip, prim = raw[:, 6], raw[:, 7]
+        skip, prim = raw[:, 6].copy(), raw[:, 7].copy()
         n = len(raw) - 1
+        byte_skip, byte_prim = skip.copy(), prim.copy()                  # node positions are byte offsets: slot number * 32
+        skip //= 32
+        prim[prim < LEAF] //= 32                                         # (an inner node's word is the position of its first child)
         assert skip[n] == n and prim[n] == n                            # sentinel: both links to itself
         is_payload = np.zeros(n + 2, bool)
         tight = f.copy()   # the boxes that have to nest: a node's own box, for exact leaves the exact box of the payload slot
@@ -441,6 +444,7 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
         if name == "final_scene":
             assert len(nodes) < 0.85 * d.n_bvh_nodes                    # 2 815 in the caller's binary tree
         for k in nodes:
+            assert byte_skip[k] % 32 == 0 and (byte_prim[k] >= LEAF or byte_prim[k] % 32 == 0)
             assert k < skip[k] <= n
             keep = ~is_payload[k + 1:skip[k]]
             if keep.any():

@@ -183,7 +183,7 @@ void twin_traverse_deferred(const rt_scene_desc* D, const rt_ray* rays, uint64_t
             }
             n_pend = 0;
         };
-        while (w.i < S.n_bvh_nodes) {
+        while (w.i < S.n_bvh_nodes * RT_NODE_STRIDE) {
             ++nodes;
             const uint32_t leaf = walk_step(S, inv, oi, 0.001f, w);
             if (leaf == RT_BVH_NONE) continue;
