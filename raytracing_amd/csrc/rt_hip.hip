@@ -126,7 +126,7 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #define RT_LEAF_BATCH 48      // run the primitive tests once this many of the 64 lanes have a leaf pending
 #endif
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 12      // fetch new rays once this many lanes are idle (a fetch waits on global memory)
+#define RT_REFILL_MIN 20      // fetch new rays once this many lanes are idle (a fetch waits on global memory)
 #endif
 #define RT_TRAV_GROUP 256u    // rays dealt to a workgroup at a time
 #ifndef RT_STUCK_MAX
