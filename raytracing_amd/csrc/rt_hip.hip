@@ -37,6 +37,11 @@ using namespace rt;
 #define RT_HIT_NONE 0xFFFFFFFFu
 
 // ------------------------------------------------------------------ device
+// Queue traffic is streamed once and is far larger than the caches: it moves with non-temporal loads and stores, which
+// leave the L2 to the scene's tables.
+typedef float NtF4 __attribute__((ext_vector_type(4)));
+typedef float NtF2 __attribute__((ext_vector_type(2)));
+typedef uint32_t NtU2 __attribute__((ext_vector_type(2)));
 struct RayQueue {
     float4* od0;  // o.x o.y o.z d.x
     float4* od1;  // d.y d.z time path(bits)
@@ -195,8 +200,8 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 #endif
             if (!active && local < my_rays && mine < count) {
                 const uint32_t at = queue_slot(mine, n_front, P.n_paths);
-                const float4 a = q.od0[at];
-                const float2 b = *reinterpret_cast<const float2*>(&q.od1[at]);
+                const NtF4 a = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&q.od0[at]));
+                const NtF2 b = __builtin_nontemporal_load(reinterpret_cast<const NtF2*>(&q.od1[at]));
                 r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y);
                 inv = walk_cap(ray_inv(r.d));  // capped for the node tests; the box leaves get the infinities back
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
@@ -256,7 +261,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             }
         }
         if (active && p0 == RT_BVH_NONE && node >= n_nodes) {
-            hits[slot] = make_uint2(best != RT_HIT_NONE ? __float_as_uint(t_end) : 0u, best);
+            __builtin_nontemporal_store(NtU2{best != RT_HIT_NONE ? __float_as_uint(t_end) : 0u, best}, reinterpret_cast<NtU2*>(&hits[slot]));
             active = false;
         }
     }
@@ -283,8 +288,11 @@ __global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParam
         Ray r; V3 thr; uint32_t path = 0, pixel = 0;
         if (i < count) {
             const uint32_t at = queue_slot(i, n_front, P.n_paths);
-            float4 a = qin.od0[at], b = qin.od1[at], c = qin.thr[at];
-            uint2 hh = hits[at];
+            const NtF4 a_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od0[at])), b_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od1[at])),
+                       c_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.thr[at]));
+            const NtU2 h_ = __builtin_nontemporal_load(reinterpret_cast<const NtU2*>(&hits[at]));
+            float4 a = make_float4(a_.x, a_.y, a_.z, a_.w), b = make_float4(b_.x, b_.y, b_.z, b_.w), c = make_float4(c_.x, c_.y, c_.z, c_.w);
+            uint2 hh = make_uint2(h_.x, h_.y);
             r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
             path = __float_as_uint(b.w);
             thr = v3(c.x, c.y, c.z);
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParam
             V3 value;
             bool hit = hh.y != RT_HIT_NONE;
             alive = shade_step(S, r, thr, key, hit, __uint_as_float(hh.x), hh.y & 0x1FFFFFFFu, (int)(hh.y >> 29), bounce + 1 >= P.max_depth, value);
-            if (!alive) values[path] = make_float4(value.x, value.y, value.z, 0.0f);
+            if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
             else to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
         }
         // compaction, per end of the queue: ballot + lane prefix inside the wave, one atomic per block and end
@@ -312,9 +320,9 @@ __global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParam
         if (alive) {
             const uint32_t k = block_base[to_front ? 0 : 1] + wave_cnt[to_front ? 0 : 1][wave] + prefix;
             const uint32_t slot = to_front ? k : P.n_paths - 1u - k;
-            qout.od0[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
-            qout.od1[slot] = make_float4(r.d.y, r.d.z, r.time, __uint_as_float(path));
-            qout.thr[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
+            __builtin_nontemporal_store(NtF4{r.o.x, r.o.y, r.o.z, r.d.x}, reinterpret_cast<NtF4*>(&qout.od0[slot]));
+            __builtin_nontemporal_store(NtF4{r.d.y, r.d.z, r.time, __uint_as_float(path)}, reinterpret_cast<NtF4*>(&qout.od1[slot]));
+            __builtin_nontemporal_store(NtF4{thr.x, thr.y, thr.z, __uint_as_float(pixel)}, reinterpret_cast<NtF4*>(&qout.thr[slot]));
         }
         __syncthreads();
     }
