@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             }
         }
         if (active && p0 == RT_BVH_NONE && node >= n_nodes) {
-            __builtin_nontemporal_store(NtU2{best != RT_HIT_NONE ? __float_as_uint(t_end) : 0u, best}, reinterpret_cast<NtU2*>(&hits[slot]));
+            hits[slot] = make_uint2(best != RT_HIT_NONE ? __float_as_uint(t_end) : 0u, best);  // (a cached store: the lanes of a wave finish at different times, the L2 gathers their 8 bytes into lines)
             active = false;
         }
     }
