@@ -159,6 +159,38 @@ def test_material_rules_by_hand():
         assert sc == 0 and np.allclose(col, img[j, i] / 255.0, rtol=1e-6), (x, y)
 
 
+def test_a_tree_too_large_for_lds():
+    """6 000 spheres and boxes: the node array (over 144 KB) stays in global memory, so the walk kernels run their other
+    variant by size and not by flag.  Closest hits against the oracle (same tree: same seed), and the rendered image
+    the same bytes whichever way a path is traced."""
+    rng = np.random.default_rng(12)
+    objs = []
+    for k in range(6000):
+        c = rng.random(3) * 200.0
+        if k % 3:
+            objs.append(rt.Object(rt.Shape.Sphere(tuple(c), 1.0 + 2.0 * rng.random()), WHITE))
+        else:
+            e = 1.0 + 3.0 * rng.random(3)
+            objs.append(rt.Object(rt.Shape.new_box(tuple(c - e), tuple(c + e)), WHITE))
+    sc = rt.Scene(objs, (1, 1, 1), seed=5)
+    osc = OracleScene(objs, (1, 1, 1), bvh_seed=5)
+    o, d, t = rays_at_box(rng, (0, 0, 0), (200, 200, 200), 6000)
+    ref = osc.intersect(o, d, t, seed=3)
+    got = sc.intersect_batch(o, d, t, seed=3)
+    nsame, _ = compare_hits(got, ref, "large tree", allow_flag_mismatch=1e-3, allow_prim_mismatch=1e-3, origins=o)
+    assert nsame > 3000
+    co = rt.CameraOptions(aperture=0.0, aspect_ratio=1.0, focus_distance=10.0, looking_at=(100, 100, 100), origin=(-150, 120, -180), shutter_close=1.0,
+                          shutter_open=0.0, vfov=40.0, vup=(0, 1, 0))
+    cam = rt.Camera(co)
+    io = rt.ImageOptions(64, 64, 16, 12)
+    _, base = sc.render(cam, io, rt.RenderOptions(seed=2), want_mean=True)
+    for flags in (_abi.RT_RENDER_NO_TAIL, _abi.RT_RENDER_TAIL_ONLY, _abi.RT_RENDER_ONE_STREAM):
+        _, m = sc.render(cam, io, rt.RenderOptions(seed=2, flags=flags), want_mean=True)
+        assert np.array_equal(m, base, equal_nan=True), flags
+    mean_o = osc.render(co.to_c(), 64, 64, 16, 12, seed=2, threads=8)[1]
+    assert rmse(np.clip(base, 0, 1), np.clip(mean_o, 0, 1)) < 0.02   # same Philox streams: the fp32 image stays next to the oracle's
+
+
 def test_empty_and_ragged_batches():
     sc = rt.Scene([rt.Object(rt.Shape.Sphere((0, 0, 0), 1.0), WHITE)], (0, 0, 0))
     assert len(sc.intersect_batch(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))) == 0
