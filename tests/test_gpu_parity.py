@@ -191,6 +191,20 @@ def test_a_tree_too_large_for_lds():
     assert rmse(np.clip(base, 0, 1), np.clip(mean_o, 0, 1)) < 0.02   # same Philox streams: the fp32 image stays next to the oracle's
 
 
+def test_a_scene_of_nothing_but_an_inert_medium():
+    """A medium bounded by a sphere can never be hit (shape.rs:386-410: both boundary queries find the same near root), so the
+    library leaves it out of its tree: the tree is empty, every ray misses and every pixel is the background."""
+    fog = rt.Object(rt.Shape.ConstantMedium(rt.Shape.Sphere((0, 0, 0), 5.0), 0.3), rt.Material.Isotropic(rt.Texture.SolidColor((1, 1, 1))))
+    co = rt.CameraOptions(aperture=0.0, aspect_ratio=1.0, focus_distance=10.0, looking_at=(0, 0, 0), origin=(0, 0, -20), shutter_close=1.0, shutter_open=0.0,
+                          vfov=40.0, vup=(0, 1, 0))
+    for keep in (False, True):
+        sc = rt.Scene([fog], (0.25, 0.5, 1.0), keep_inert=keep)
+        h = sc.intersect_batch([[0, 0, -20]], [[0, 0, 1]], [0.0])
+        assert h[0]["hit"] == 0
+        rgb, mean = sc.render(rt.Camera(co), rt.ImageOptions(16, 16, 4, 5), rt.RenderOptions(seed=1), want_mean=True)
+        assert np.allclose(mean, [0.25, 0.5, 1.0]) and (rgb.reshape(-1, 3) == [127, 181, 255]).all()   # sqrt(x) * 255.999 truncated (lib.rs:68-72)
+
+
 def test_empty_and_ragged_batches():
     sc = rt.Scene([rt.Object(rt.Shape.Sphere((0, 0, 0), 1.0), WHITE)], (0, 0, 0))
     assert len(sc.intersect_batch(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))) == 0
