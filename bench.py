@@ -144,8 +144,7 @@ def main():
         # trace of `bench.py --spp 104 --one-stream` averages over launches of exactly this kind)
         prof_io = rt.ImageOptions(HEIGHT, WIDTH, min(104, args.spp), DEPTH)
         dmean = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.float64, device="cuda")
-        scene.render_device(cam, prof_io, rt.RenderOptions(seed=1, rank=0, world_size=world, tile_w=16, tile_h=16, flags=_abi.RT_RENDER_PROFILE,
-                                                           stream=torch.cuda.current_stream().cuda_stream), dmean.data_ptr())
+        scene.render_device(cam, prof_io, rt.RenderOptions(seed=1, rank=0, world_size=world, tile_w=16, tile_h=16, flags=_abi.RT_RENDER_PROFILE), dmean.data_ptr())
         torch.cuda.synchronize()
         prof = scene.profile()
         roofline, cpu = None, None

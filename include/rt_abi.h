@@ -204,14 +204,18 @@ typedef struct rt_render_options {
     uint32_t tile_w, tile_h;  /* 0 = default 16 x 16 */
     uint32_t samples_per_pass;/* 0 = automatic; does not change the result */
     uint32_t flags;           /* RT_RENDER_* */
-    void* stream;             /* hipStream_t to launch on; NULL = the library's own stream */
+    void* stream;             /* hipStream_t to launch on; NULL = the library's own (non-blocking) stream, which has no
+                                 order with the null stream or any other: a caller that works on the legacy default
+                                 stream passes a stream of its own and orders the two with events */
 } rt_render_options;
 enum {
     RT_RENDER_PROFILE = 1u,  /* time every kernel launch with HIP events (rt_get_profile) */
     RT_RENDER_NO_TAIL = 2u,  /* every bounce as separate traverse / shade launches (same image; for tests) */
     RT_RENDER_TAIL_ONLY = 4u, /* every path runs start to end in the tail kernel (same image; for tests) */
     RT_RENDER_NODES_IN_GLOBAL = 8u, /* walk the BVH in global memory even when it would fit in LDS (same image; for tests) */
-    RT_RENDER_ONE_STREAM = 16u /* never split a pass into two halves on two streams (same image; for tests and clean kernel timings) */
+    RT_RENDER_ONE_STREAM = 16u, /* never split a pass into two halves on two streams (same image; for tests and clean kernel timings) */
+    RT_RENDER_RECALIBRATE = 32u /* measure the frame's schedule again (where the tail kernel takes over, whether two streams
+                                   pay) instead of reusing what an earlier frame of the same shape on this handle learnt */
 };
 
 typedef struct rt_scene rt_scene; /* opaque */

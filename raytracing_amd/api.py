@@ -261,7 +261,21 @@ class RenderOptions:
     stream: Optional[int] = None
 
     def to_c(self):
+        # A stream handle of 0 is torch's default stream, but the ABI reads NULL as "the library's own stream", which has no
+        # order with the default stream: refuse it rather than run unordered.  None asks for the library's stream by name.
+        if self.stream is not None and int(self.stream) == 0:
+            raise ValueError("stream handle 0 (the default stream) cannot be named through the ABI: pass None for the library's own stream, "
+                             "or the handle of a torch.cuda.Stream")
         return _abi.rt_render_options(self.seed, self.rank, self.world_size, self.tile_w, self.tile_h, self.samples_per_pass, self.flags, self.stream)
+
+
+def _current_device() -> int:
+    """The device index torch has current in this thread (what tensors named "cuda" land on); 0 when torch is not in use."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        return int(torch.cuda.current_device())
+    return 0
 
 
 def rays_to_c(origins, directions, times):
@@ -286,7 +300,7 @@ class Scene:
     def __init__(self, objects: List[Object], background_color, seed: int = 1, keep_inert: bool = False, _handle=None):
         self._host = _abi.host_lib()
         self._hip = _abi.hip_lib()
-        self._dev = None
+        self._dev = {}
         if _handle is not None:
             self._h = _handle
             return
@@ -325,17 +339,19 @@ class Scene:
         return self._host.rth_scene_desc(self._h).contents
 
     def device(self, device: int = -1):
-        """rt_scene handle on a HIP device (created on first use).  Raises RtError without a GPU."""
-        if self._dev is None:
+        """rt_scene handle on HIP device `device` (-1: the device torch has current, else device 0), created on first use
+        and kept per device.  Raises RtError without a GPU."""
+        if device < 0:
+            device = _current_device()
+        if device not in self._dev:
             out = C.c_void_p()
             _abi.check(self._hip.rt_scene_create(self._host.rth_scene_desc(self._h), device, C.byref(out)))
-            self._dev = out
-        return self._dev
+            self._dev[device] = out
+        return self._dev[device]
 
     def close(self):
-        if getattr(self, "_dev", None):
-            self._hip.rt_scene_destroy(self._dev)
-            self._dev = None
+        for dev in list(getattr(self, "_dev", None) or {}):
+            self._hip.rt_scene_destroy(self._dev.pop(dev))
         if getattr(self, "_h", None):
             self._host.rth_scene_free(self._h)
             self._h = None
@@ -364,6 +380,9 @@ class Scene:
         _abi.check(self._hip.rt_render_device(self.device(), C.byref(camera.abi), C.byref(io), C.byref(ro), C.c_void_p(d_mean_ptr)))
 
     def quantise_device(self, d_mean_ptr: int, n: int, d_rgb_ptr: int, stream: Optional[int] = None):
+        """rt_quantise_device on `stream` (a real stream handle; None = the library's own stream, see RenderOptions.to_c)."""
+        if stream is not None and int(stream) == 0:
+            raise ValueError("stream handle 0 (the default stream) cannot be named through the ABI")
         _abi.check(self._hip.rt_quantise_device(self.device(), C.c_void_p(d_mean_ptr), n, C.c_void_p(d_rgb_ptr), stream))
 
     def profile(self) -> dict:

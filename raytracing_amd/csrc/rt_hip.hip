@@ -101,11 +101,48 @@ __global__ void __launch_bounds__(RT_BS) k_raygen(PassParams P, RayQueue q, uint
     q.thr[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
 }
 
+// The pixels this rank owns, tile by tile (tile_id = ty * ntx + tx, owner = tile_id % world_size), rows of a tile bottom-up
+// and left to right: owned[k] = j * width + i.  One workgroup: every thread takes a tile, a scan over the tiles' pixel
+// counts gives each its place in the list.  (The order of the list only lays out the workspace; every draw is keyed by
+// the pixel's number in the frame.)
+__global__ void __launch_bounds__(1024) k_owned_list(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world, uint32_t* owned) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t running;
+    const uint32_t ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th, ntiles = ntx * nty, tid = threadIdx.x;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 1024u) {
+        const uint32_t tile = base + tid;
+        uint32_t cnt = 0, x0 = 0, y0 = 0, cw = 0, ch = 0;
+        if (tile < ntiles && tile % world == rank) {
+            x0 = (tile % ntx) * tw; y0 = (tile / ntx) * th;
+            cw = min(tw, W - x0); ch = min(th, H - y0);
+            cnt = cw * ch;
+        }
+        part[tid] = cnt;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024u; off <<= 1) {  // inclusive scan
+            const uint32_t v = tid >= off ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        uint32_t at = running + part[tid] - cnt;
+        for (uint32_t y = 0; y < ch; ++y)
+            for (uint32_t x = 0; x < cw; ++x) owned[at++] = (y0 + y) * W + x0 + x;
+        __syncthreads();
+        if (tid == 1023u) running += part[1023];
+        __syncthreads();
+    }
+}
+
 // BVH nodes staged into LDS: each workgroup copies the node array once per launch and every ray of the
 // launch walks it there.  The walk is a chain of dependent 32-byte node reads at a different address in
 // every lane; from the vector L1 that costs a cache-line lookup per lane per step, from LDS a banked read.
 // NODES_IN_LDS = false is the same kernel reading the nodes from global memory (trees too large for LDS).
 #define RT_TRAV_BS 1024
+#define RT_LDS_NODE_LIMIT (144u * 1024u)  // dynamic LDS the walk kernels may ask for
+#define RT_LDS_BEHIND_NODES 16u           // k_traverse keeps its ray counter behind the node array
 template <bool NODES_IN_LDS>
 __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds) {
     SceneView V = S;
@@ -458,24 +495,33 @@ static rt_status fail(rt_status s, const std::string& m) { g_err = m; return s; 
 #define RT_PASS_PARTS 2   // parts a pass is split into when splitting pays (each on a stream of its own)
 #endif
 #define RT_MAX_PARTS 4
-struct rt_scene {
-    int device = 0;
-    SceneView view{};
-    std::vector<void*> allocs;
-    hipStream_t own_stream = nullptr, side_stream[RT_MAX_PARTS - 1] = {};  // side streams: the other parts of a pass (see render_impl)
-    hipEvent_t ev_fork = nullptr, ev_join[RT_MAX_PARTS - 1] = {};
-    bool lds_attr_set = false;
-    // workspace
-    uint64_t ws_paths = 0, ws_pixels = 0;
+// Device memory of a render beyond its inputs and outputs: sized for one pass of `paths` paths over `pixels` owned pixels.
+struct Workspace {
+    uint64_t paths = 0, pixels = 0;
+    uint32_t n_counts = 0;          // queue lengths: RT_MAX_PARTS x 2 arrays of this many entries
     RayQueue q[2]{};
     uint2* hits = nullptr;
     float4* values = nullptr;
     double* accum = nullptr;
     uint32_t* owned = nullptr;
     uint32_t* counts = nullptr;
-    uint32_t n_counts = 0;
+};
+// What the first pass of a frame learns by reading queue lengths back and timing its kernels, kept per frame shape so
+// that repeat frames (and every frame of a rank with a small share) run without a host round trip.  It only schedules:
+// the image does not depend on it.
+struct Calibration { uint32_t width, height, depth, n_owned; int tail_from; bool split_pays; };
+struct rt_scene {
+    int device = 0;
+    uint32_t n_cu = 0;
+    SceneView view{};
+    std::vector<void*> allocs;
+    hipStream_t own_stream = nullptr, side_stream[RT_MAX_PARTS - 1] = {};  // side streams: the other parts of a pass (see render_impl)
+    hipEvent_t ev_fork = nullptr, ev_join[RT_MAX_PARTS - 1] = {};
+    bool nodes_fit_lds = false;
+    Workspace ws;
     uint32_t* h_counts = nullptr;  // pinned
     std::vector<void*> ws_allocs;
+    std::vector<Calibration> calibrations;
     // profile
     rt_profile prof{};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> events;
@@ -498,7 +544,7 @@ static rt_status validate_desc(const rt_scene_desc* D) {
     if (!D) return fail(RT_ERR_INVALID_ARGUMENT, "scene description is null");
     if (D->abi_version != RT_ABI_VERSION) return fail(RT_ERR_INVALID_ARGUMENT, "abi_version mismatch");
     if (D->n_prims == 0) return fail(RT_ERR_EMPTY_SCENE, "a scene needs at least one object (Scene::new asserts this)");
-    if (D->n_prims >= (1u << 21)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");  // (node positions, in bytes, stay below RT_NODE_LEAF)
+    if (D->n_prims >= (1u << 21)) return fail(RT_ERR_UNSUPPORTED, "too many primitives");
     if (!D->prims || !D->materials || D->n_materials == 0) return fail(RT_ERR_INVALID_ARGUMENT, "prims / materials missing");
     if ((D->n_spheres && !D->spheres) || (D->n_rects && !D->rects) || (D->n_boxes && !D->boxes) || (D->n_xforms && !D->xforms) ||
         (D->n_textures && !D->textures) || (D->n_images && !D->images) || (D->n_perm_tables && !D->perm_tables) || (D->n_bvh_nodes && !D->bvh))
@@ -575,7 +621,7 @@ static void free_workspace(rt_scene* sc) {
     for (void* p : sc->ws_allocs) (void)hipFree(p);
     sc->ws_allocs.clear();
     if (sc->h_counts) { (void)hipHostFree(sc->h_counts); sc->h_counts = nullptr; }
-    sc->ws_paths = sc->ws_pixels = 0; sc->n_counts = 0;
+    sc->ws = Workspace{};
 }
 
 extern "C" {
@@ -636,6 +682,10 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     {   // the walk's own node array (payload slots, leaf annotations, sentinel)
         std::vector<WalkNode> nodes;
         make_walk_nodes(D, nodes);
+        if (nodes.size() * sizeof(WalkNode) >= RT_NODE_LEAF) {  // node positions are byte offsets and share a word with the leaf bits
+            rt_scene_destroy(sc);
+            return fail(RT_ERR_UNSUPPORTED, "BVH too large: node positions must stay below 2^28 bytes");
+        }
         UP(bvh, nodes.data(), nodes.size());
         V.n_bvh_nodes = (uint32_t)nodes.size() - 1;
     }
@@ -647,6 +697,21 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming);
     for (auto& x : sc->ev_join) if (e == hipSuccess) e = hipEventCreateWithFlags(&x, hipEventDisableTiming);
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("stream / event creation: ") + hipGetErrorString(e)); }
+    // The node array goes to LDS when it fits beside the workgroup's ray counter (160 KB per CU, one 1024-thread workgroup
+    // per CU): the walk kernels then take the start of their dynamic LDS for address 0 (walk_step_flat).
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e)); }
+    sc->n_cu = (uint32_t)prop.multiProcessorCount;
+    const size_t node_bytes = ((size_t)V.n_bvh_nodes + 1) * sizeof(WalkNode);
+    sc->nodes_fit_lds = V.n_bvh_nodes > 0 && node_bytes + RT_LDS_BEHIND_NODES <= RT_LDS_NODE_LIMIT;
+    if (sc->nodes_fit_lds) {
+        hipFuncAttributes fa;
+        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_traverse<true>));
+        if (e == hipSuccess && fa.sharedSizeBytes != 0) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array"); }
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
+        if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
+    }
     *out = sc;
     return RT_OK;
 }
@@ -654,7 +719,8 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
 }  // extern "C"
 
 static rt_status ensure_workspace(rt_scene* sc, uint64_t n_paths, uint64_t n_pixels, uint32_t n_counts) {
-    if (n_paths <= sc->ws_paths && n_pixels <= sc->ws_pixels && n_counts <= sc->n_counts) return RT_OK;
+    Workspace& w = sc->ws;
+    if (n_paths <= w.paths && n_pixels <= w.pixels && n_counts <= w.n_counts) return RT_OK;
     free_workspace(sc);
     n_paths = std::max<uint64_t>(n_paths, 1); n_pixels = std::max<uint64_t>(n_pixels, 1);
     auto alloc = [&](void** p, size_t bytes) -> rt_status {
@@ -664,17 +730,17 @@ static rt_status ensure_workspace(rt_scene* sc, uint64_t n_paths, uint64_t n_pix
     };
     rt_status st;
     for (int k = 0; k < 2; ++k) {
-        if ((st = alloc((void**)&sc->q[k].od0, n_paths * sizeof(float4))) != RT_OK) return st;
-        if ((st = alloc((void**)&sc->q[k].od1, n_paths * sizeof(float4))) != RT_OK) return st;
-        if ((st = alloc((void**)&sc->q[k].thr, n_paths * sizeof(float4))) != RT_OK) return st;
+        if ((st = alloc((void**)&w.q[k].od0, n_paths * sizeof(float4))) != RT_OK) return st;
+        if ((st = alloc((void**)&w.q[k].od1, n_paths * sizeof(float4))) != RT_OK) return st;
+        if ((st = alloc((void**)&w.q[k].thr, n_paths * sizeof(float4))) != RT_OK) return st;
     }
-    if ((st = alloc((void**)&sc->hits, n_paths * sizeof(uint2))) != RT_OK) return st;
-    if ((st = alloc((void**)&sc->values, n_paths * sizeof(float4))) != RT_OK) return st;
-    if ((st = alloc((void**)&sc->accum, n_pixels * 3 * sizeof(double))) != RT_OK) return st;
-    if ((st = alloc((void**)&sc->owned, n_pixels * sizeof(uint32_t))) != RT_OK) return st;
-    if ((st = alloc((void**)&sc->counts, RT_MAX_PARTS * 2 * (size_t)n_counts * sizeof(uint32_t))) != RT_OK) return st;  // per part of a pass: front and back lengths
+    if ((st = alloc((void**)&w.hits, n_paths * sizeof(uint2))) != RT_OK) return st;
+    if ((st = alloc((void**)&w.values, n_paths * sizeof(float4))) != RT_OK) return st;
+    if ((st = alloc((void**)&w.accum, n_pixels * 3 * sizeof(double))) != RT_OK) return st;
+    if ((st = alloc((void**)&w.owned, n_pixels * sizeof(uint32_t))) != RT_OK) return st;
+    if ((st = alloc((void**)&w.counts, RT_MAX_PARTS * 2 * (size_t)n_counts * sizeof(uint32_t))) != RT_OK) return st;  // per part of a pass: front and back lengths
     HIP_TRY(hipHostMalloc((void**)&sc->h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
-    sc->ws_paths = n_paths; sc->ws_pixels = n_pixels; sc->n_counts = n_counts;
+    w.paths = n_paths; w.pixels = n_pixels; w.n_counts = n_counts;
     return RT_OK;
 }
 
@@ -725,29 +791,44 @@ static rt_status validate_render(rt_scene* sc, const rt_camera* cam, const rt_im
     return RT_OK;
 }
 
+// Number of pixels in the tiles rank `rank` owns (tile_id % world_size == rank), without listing them.
+static uint64_t count_owned(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world) {
+    const uint32_t ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th;
+    uint64_t n = 0;
+    for (uint32_t ty = 0; ty < nty; ++ty) {
+        const uint64_t ch = std::min(th, H - ty * th);
+        for (uint32_t tx = 0; tx < ntx; ++tx)
+            if ((ty * ntx + tx) % world == rank) n += ch * std::min(tw, W - tx * tw);
+    }
+    return n;
+}
+
 // Renders this rank's pixels into d_mean_out (full frame of doubles on the device).
-static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out, bool sync_at_end) {
+// `fixed`: the workspace of the variant that allocates nothing (null: the scene handle's own, grown as needed).  That
+// variant also creates no events and reads nothing back: it hands over to k_tail at a bounce fixed in advance.
+static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out, bool sync_at_end,
+                             const Workspace* fixed) {
     rt_status st = validate_render(sc, cam, io, ro);
     if (st != RT_OK) return st;
     if (!d_mean_out) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is null");
     HIP_TRY(hipSetDevice(sc->device));
     hipStream_t stream = ro->stream ? (hipStream_t)ro->stream : sc->own_stream;
     const bool profile = (ro->flags & RT_RENDER_PROFILE) != 0;
+    if (fixed && profile) return fail(RT_ERR_INVALID_ARGUMENT, "RT_RENDER_PROFILE creates events: not available without allocation");
     const uint32_t W = io->width, H = io->height;
     const uint32_t tw = ro->tile_w ? ro->tile_w : 16, th = ro->tile_h ? ro->tile_h : 16;
-    const uint32_t ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th;
-
-    // pixels of the tiles this rank owns, tile by tile (tile_id % world_size == rank)
-    std::vector<uint32_t> owned;
-    for (uint32_t ty = 0; ty < nty; ++ty)
-        for (uint32_t tx = 0; tx < ntx; ++tx) {
-            if ((ty * ntx + tx) % ro->world_size != ro->rank) continue;
-            for (uint32_t y = ty * th; y < std::min(H, (ty + 1) * th); ++y)
-                for (uint32_t x = tx * tw; x < std::min(W, (tx + 1) * tw); ++x) owned.push_back(y * W + x);
-        }
-    const uint32_t n_owned = (uint32_t)owned.size();
+    if ((uint64_t)((W + tw - 1) / tw) * ((H + th - 1) / th) >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many tiles");
     const uint64_t spp = io->samples_per_pixel;
     const uint32_t depth = (uint32_t)io->max_reflections;
+    const uint32_t n_counts = depth + 2;
+    const uint64_t n_owned64 = count_owned(W, H, tw, th, ro->rank, ro->world_size);
+    if (fixed && (n_owned64 > fixed->pixels || n_counts > fixed->n_counts)) {
+        char msg[200];
+        snprintf(msg, sizeof(msg), "the fixed workspace holds at most %llu pixels per rank and max_reflections %u (this frame: %llu pixels, %u)",
+                 (unsigned long long)fixed->pixels, fixed->n_counts - 2u, (unsigned long long)n_owned64, depth);
+        return fail(RT_ERR_UNSUPPORTED, msg);
+    }
+    const uint32_t n_owned = (uint32_t)n_owned64;
 
     HIP_TRY(hipMemsetAsync(d_mean_out, 0, (size_t)3 * W * H * sizeof(double), stream));
     std::memset(&sc->prof, 0, sizeof(sc->prof));
@@ -762,41 +843,31 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const bool auto_pass = S == 0;
     if (auto_pass) S = std::max<uint64_t>(1, (64ull << 20) / n_owned);
     S = std::min<uint64_t>(S, spp);
+    if (fixed) S = std::min<uint64_t>(S, fixed->paths / n_owned);  // (at least 1: n_owned <= pixels <= paths)
     while (S > 1 && S * n_owned >= (1ull << 31)) S /= 2;
     if (S * n_owned >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many pixels per rank for one pass");
-    const uint32_t n_counts = depth + 2;
-    while ((st = ensure_workspace(sc, S * n_owned, n_owned, n_counts)) != RT_OK) {
+    while (!fixed && (st = ensure_workspace(sc, S * n_owned, n_owned, n_counts)) != RT_OK) {
         if (st != RT_ERR_OUT_OF_MEMORY || !auto_pass || S == 1) return st;
         (void)hipGetLastError();  // the failed allocation is not an error of the render
         S = (S + 1) / 2;
     }
-    HIP_TRY(hipMemcpyAsync(sc->owned, owned.data(), n_owned * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemsetAsync(sc->accum, 0, (size_t)n_owned * 3 * sizeof(double), stream));
-    HIP_TRY(hipStreamSynchronize(stream));  // `owned` is a stack vector
+    const Workspace& ws = fixed ? *fixed : sc->ws;
+    hipLaunchKernelGGL(k_owned_list, dim3(1), dim3(1024), 0, stream, W, H, tw, th, ro->rank, ro->world_size, ws.owned);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(ws.accum, 0, (size_t)n_owned * 3 * sizeof(double), stream));
 
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
-    const uint32_t max_grid = (uint32_t)prop.multiProcessorCount * 8u;
-    // The node array goes to LDS when it fits beside nothing else (160 KB per CU, one 1024-thread workgroup per CU).
+    const uint32_t max_grid = sc->n_cu * 8u;
     const size_t node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
-    const bool nodes_in_lds = sc->view.n_bvh_nodes > 0 && node_bytes <= 144u * 1024u && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
-    if (nodes_in_lds && !sc->lds_attr_set) {
-        hipFuncAttributes fa;  // k_traverse takes the start of its dynamic LDS for address 0 (walk_step_flat)
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_traverse<true>)));
-        if (fa.sharedSizeBytes != 0) return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array");
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        sc->lds_attr_set = true;
-    }
-    const uint32_t tail_threshold = (uint32_t)prop.multiProcessorCount * 512u;
+    const bool nodes_in_lds = sc->nodes_fit_lds && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
+    const uint32_t tail_threshold = sc->n_cu * 512u;
     Launcher L{sc, stream, profile};
     hipEvent_t ev;
 
     PassParams P;
     P.cam = *cam; P.width = W; P.height = H; P.n_owned = n_owned;
     P.owned_magic = n_owned > 1 ? ~0ull / n_owned + 1 : 0;
-    P.k0 = (uint32_t)ro->seed; P.k1 = (uint32_t)(ro->seed >> 32); P.max_depth = depth; P.owned = sc->owned;
-    P.n_counts = depth + 2;
+    P.k0 = (uint32_t)ro->seed; P.k1 = (uint32_t)(ro->seed >> 32); P.max_depth = depth; P.owned = ws.owned;
+    P.n_counts = n_counts;
     P.up_axis = 1;
     for (uint32_t c = 0; c < 3; ++c) if (std::fabs(cam->v[c]) > std::fabs(cam->v[P.up_axis])) P.up_axis = c;
     P.up_sign = cam->v[P.up_axis] < 0.0 ? -1.0f : 1.0f;
@@ -804,19 +875,29 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;
     int tail_from = force_tail ? 0 : -1;  // bounce at which k_tail takes over; -1 = not calibrated yet
     bool split_pays = false;               // set by the calibrating pass: traversal dominates shading
+    Calibration* known = nullptr;
+    for (auto& c : sc->calibrations)
+        if (c.width == W && c.height == H && c.depth == depth && c.n_owned == n_owned) known = &c;
+    if (fixed && tail_from < 0 && !force_wavefront) {
+        // nothing is read back: queues of a pass this small are short after a bounce or two
+        tail_from = S * n_owned > tail_threshold ? (int)std::min<uint32_t>(depth, 2u) : 0;
+    } else if (known && tail_from < 0 && !force_wavefront && !profile && !(ro->flags & RT_RENDER_RECALIBRATE)) {
+        tail_from = known->tail_from; split_pays = known->split_pays;
+    }
 
     // A pass runs as one or two independent halves (its samples split in two), each with its own queues and counters:
     // traversal is bound by instruction issue and shading by memory traffic, so the two halves, launched on two streams,
     // fill each other's gaps (the shading waves of one fit beside the traversal workgroup of the other on a CU).
-    // Passes that read queue lengths back (the first, profiled ones, RT_RENDER_NO_TAIL) run as one half on one stream.
+    // Passes that read queue lengths back (the first of a new frame shape, profiled ones, RT_RENDER_NO_TAIL) run as one
+    // half on one stream.
     struct Half {
         hipStream_t stream; PassParams P; RayQueue q[2]; uint2* hits; uint32_t* counts; float4* values; int cur;
     };
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
-            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes + 16, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes + RT_LDS_BEHIND_NODES, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
         else
-            hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), 16, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+            hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), RT_LDS_BEHIND_NODES, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
     };
     auto launch_tail = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
@@ -830,10 +911,10 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         const uint32_t ns = (uint32_t)std::min<uint64_t>(S, spp - s0);
         // Queue lengths are read back (one sync per bounce) only while the hand-over point to k_tail is
         // still unknown, when profiling, or when k_tail is disabled; otherwise nothing waits on the host.
-        const bool readback = tail_from < 0 || profile || force_wavefront;
-        const bool calibrating = tail_from < 0 && !profile;  // this pass also times its kernels, to see whether splitting later passes pays
+        const bool readback = !fixed && (tail_from < 0 || profile || force_wavefront);
+        const bool calibrating = !fixed && tail_from < 0 && !profile;  // this pass also times its kernels, to see whether splitting later passes pays
         L.profile = profile || calibrating;
-        const int n_halves = (!readback && split_pays && ns >= RT_PASS_PARTS && !(ro->flags & RT_RENDER_ONE_STREAM)) ? RT_PASS_PARTS : 1;
+        const int n_halves = (!fixed && !readback && split_pays && ns >= RT_PASS_PARTS && !(ro->flags & RT_RENDER_ONE_STREAM)) ? RT_PASS_PARTS : 1;
         Half half[RT_MAX_PARTS];
         uint32_t sample_off = 0;
         for (int k = 0; k < n_halves; ++k) {
@@ -842,8 +923,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             const size_t path_off = (size_t)sample_off * n_owned;
             h.stream = k == 0 ? stream : sc->side_stream[k - 1];
             h.P = P; h.P.sample_base = (uint32_t)s0 + sample_off; h.P.n_paths = ns_k * n_owned;
-            for (int j = 0; j < 2; ++j) { h.q[j].od0 = sc->q[j].od0 + path_off; h.q[j].od1 = sc->q[j].od1 + path_off; h.q[j].thr = sc->q[j].thr + path_off; }
-            h.hits = sc->hits + path_off; h.counts = sc->counts + (size_t)k * 2 * n_counts; h.values = sc->values + path_off; h.cur = 0;
+            for (int j = 0; j < 2; ++j) { h.q[j].od0 = ws.q[j].od0 + path_off; h.q[j].od1 = ws.q[j].od1 + path_off; h.q[j].thr = ws.q[j].thr + path_off; }
+            h.hits = ws.hits + path_off; h.counts = ws.counts + (size_t)k * 2 * n_counts; h.values = ws.values + path_off; h.cur = 0;
             sample_off += ns_k;
         }
         if (n_halves > 1) {  // the other streams start after everything queued so far (the previous pass's resolve reads `values`)
@@ -856,7 +937,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             const uint32_t grid_full = (h.P.n_paths + RT_BS - 1) / RT_BS;
             grid[k] = std::min(grid_full, max_grid);
             shade_grid[k] = std::min((h.P.n_paths + RT_SHADE_BS - 1) / RT_SHADE_BS, max_grid * RT_BS / RT_SHADE_BS);
-            trav_grid[k] = std::min((h.P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, (uint32_t)prop.multiProcessorCount);
+            trav_grid[k] = std::min((h.P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, sc->n_cu);
             if (k == 0 && (st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
             hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, h.stream, h.P, h.q[0], h.counts, n_counts);
             if (k == 0 && (st = L.end(ev)) != RT_OK) return st;
@@ -908,7 +989,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             HIP_TRY(hipStreamWaitEvent(stream, sc->ev_join[k - 1], 0));
         }
         if ((st = L.begin(RT_K_RESOLVE, &ev)) != RT_OK) return st;
-        hipLaunchKernelGGL(k_resolve, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, sc->values, sc->accum, n_owned, ns);
+        hipLaunchKernelGGL(k_resolve, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, ws.values, ws.accum, n_owned, ns);
         if ((st = L.end(ev)) != RT_OK) return st;
         if (calibrating) {
             // Two halves on two streams pay when the instruction-bound traversal dominates the memory-bound shading (they
@@ -919,11 +1000,16 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             if ((st = collect_profile(sc)) != RT_OK) return st;
             split_pays = sc->prof.kernel_ms[RT_K_TRAVERSE] - keep.kernel_ms[RT_K_TRAVERSE] > 1.5 * (sc->prof.kernel_ms[RT_K_SHADE] - keep.kernel_ms[RT_K_SHADE]);
             sc->prof = keep;
+            if (!force_wavefront && !force_tail && ns == S) {  // (a full-size pass: what it saw holds for the passes to come)
+                const Calibration c{W, H, depth, n_owned, tail_from, split_pays};
+                if (known) *known = c;
+                else { if (sc->calibrations.size() >= 64) sc->calibrations.erase(sc->calibrations.begin()); sc->calibrations.push_back(c); known = &sc->calibrations.back(); }
+            }
         }
     }
     L.profile = profile;
     if ((st = L.begin(RT_K_FINALIZE, &ev)) != RT_OK) return st;
-    hipLaunchKernelGGL(k_finalize, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, sc->accum, sc->owned, n_owned, W, H, (double)spp, d_mean_out);
+    hipLaunchKernelGGL(k_finalize, dim3((n_owned + RT_BS - 1) / RT_BS), dim3(RT_BS), 0, stream, ws.accum, ws.owned, n_owned, W, H, (double)spp, d_mean_out);
     if ((st = L.end(ev)) != RT_OK) return st;
     if (sync_at_end || profile) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -935,7 +1021,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
 extern "C" {
 
 rt_status rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out) {
-    return render_impl(sc, cam, io, ro, d_mean_out, false);
+    return render_impl(sc, cam, io, ro, d_mean_out, false, nullptr);
 }
 
 rt_status rt_quantise_device(rt_scene* sc, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream) {
@@ -957,7 +1043,7 @@ rt_status rt_render(rt_scene* sc, const rt_camera* cam, const rt_image_options* 
     double* d_mean = nullptr; uint8_t* d_rgb = nullptr;
     HIP_TRY(hipMalloc((void**)&d_mean, n * sizeof(double)));
     hipStream_t stream = ro->stream ? (hipStream_t)ro->stream : sc->own_stream;
-    st = render_impl(sc, cam, io, ro, d_mean, false);
+    st = render_impl(sc, cam, io, ro, d_mean, false, nullptr);
     if (st == RT_OK && rgb_out) {
         hipError_t e = hipMalloc((void**)&d_rgb, n);
         if (e != hipSuccess) st = fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(rgb)");

@@ -6,6 +6,13 @@ take part.  The only exchange is one sum-reduce of the full-frame f64 mean-radia
 rank 0 (RCCL over xGMI when the process group's backend is "nccl"): every rank holds zeros for
 the pixels it does not own, and adding zeros is exact, so the gathered frame is bit-identical to a
 single-rank render.
+
+Stream order.  The library launches on the stream it is given; a NULL handle means its own
+non-blocking stream, which has no order with torch's streams -- and the handle of torch's default
+stream IS 0.  The render and the quantisation therefore run on a torch side stream of this module
+(one per device, a real handle), joined to torch's current stream by events on both sides, so
+that the collective (ordered after the current stream) reads a finished frame and the caller only
+ever has to synchronise the current stream.
 """
 import numpy as np
 import torch
@@ -14,6 +21,16 @@ import torch.distributed as dist
 from .api import Camera, ImageOptions, RenderOptions, Scene
 
 TILE_W = TILE_H = 16
+
+_side_streams = {}
+
+
+def render_stream(device: torch.device) -> torch.cuda.Stream:
+    """The side stream renders run on (one per device, created on first use)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _side_streams:
+        _side_streams[idx] = torch.cuda.Stream(device=idx)
+    return _side_streams[idx]
 
 
 def owned_mask(width, height, rank, world_size, tile_w=TILE_W, tile_h=TILE_H):
@@ -36,21 +53,43 @@ def gather_frames(local_mean: torch.Tensor, dst: int = 0, group=None) -> torch.T
     return local_mean
 
 
+def render_local(scene: Scene, camera: Camera, image_options: ImageOptions, seed: int = 1, rank: int = 0, world_size: int = 1, flags: int = 0) -> torch.Tensor:
+    """This rank's tiles as a full frame of f64 means (zeros elsewhere) on the current device.  The work runs on the
+    module's side stream; on return torch's current stream is ordered after it, so the tensor can be used there
+    (and by collectives) without a device-wide synchronisation."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    h, w = image_options.height, image_options.width
+    cur, side = torch.cuda.current_stream(dev), render_stream(dev)
+    mean = torch.empty((h, w, 3), dtype=torch.float64, device=dev)
+    side.wait_stream(cur)          # (the allocator may hand out memory that work queued on `cur` still uses)
+    mean.record_stream(side)
+    ro = RenderOptions(seed=seed, rank=rank, world_size=world_size, tile_w=TILE_W, tile_h=TILE_H, flags=flags, stream=side.cuda_stream)
+    scene.render_device(camera, image_options, ro, mean.data_ptr())
+    cur.wait_stream(side)
+    return mean
+
+
+def quantise(scene: Scene, mean: torch.Tensor) -> torch.Tensor:
+    """lib.rs:68-72 on a device frame of means: uint8 tensor of the same shape, ordered on torch's current stream."""
+    dev = mean.device
+    cur, side = torch.cuda.current_stream(dev), render_stream(dev)
+    rgb = torch.empty(mean.shape, dtype=torch.uint8, device=dev)
+    side.wait_stream(cur)          # the frame may still be being reduced on `cur`
+    rgb.record_stream(side)
+    mean.record_stream(side)
+    scene.quantise_device(mean.data_ptr(), mean.numel(), rgb.data_ptr(), side.cuda_stream)
+    cur.wait_stream(side)
+    return rgb
+
+
 def render_distributed(scene: Scene, camera: Camera, image_options: ImageOptions, seed: int = 1, flags: int = 0, group=None):
     """Renders this rank's tiles on the current CUDA/HIP device, gathers on rank 0.
     Returns (rgb uint8 (h, w, 3) device tensor, mean f64 device tensor) on rank 0 and (None, local mean) elsewhere.
-    Everything is enqueued on torch's current stream; the caller synchronises."""
+    Everything is ordered on torch's current stream when this returns; the caller synchronises that stream."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    dev = torch.device("cuda", torch.cuda.current_device())
-    h, w = image_options.height, image_options.width
-    mean = torch.empty((h, w, 3), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    ro = RenderOptions(seed=seed, rank=rank, world_size=world, tile_w=TILE_W, tile_h=TILE_H, flags=flags, stream=stream)
-    scene.render_device(camera, image_options, ro, mean.data_ptr())
+    mean = render_local(scene, camera, image_options, seed, rank, world, flags)
     gather_frames(mean, 0, group)
     if rank != 0:
         return None, mean
-    rgb = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
-    scene.quantise_device(mean.data_ptr(), 3 * h * w, rgb.data_ptr(), stream)
-    return rgb, mean
+    return quantise(scene, mean), mean

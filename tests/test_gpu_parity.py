@@ -382,9 +382,36 @@ def test_quantise_device_matches_reference_rule():
     sc = rt.Scene([rt.Object(rt.Shape.Sphere((0, 0, 0), 1.0), WHITE)], (0, 0, 0))
     vals = torch.tensor([0.25, 1.0, 4.0, -0.5, float("nan"), 0.0, 1e-9, 0.9999999], dtype=torch.float64, device="cuda")
     out = torch.zeros(8, dtype=torch.uint8, device="cuda")
-    sc.quantise_device(vals.data_ptr(), 8, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())   # the fill of `out` is queued on the current stream
+    sc.quantise_device(vals.data_ptr(), 8, out.data_ptr(), side.cuda_stream)
+    with pytest.raises(ValueError):                 # handle 0 would mean the library's own, unordered stream
+        sc.quantise_device(vals.data_ptr(), 8, out.data_ptr(), 0)
     torch.cuda.synchronize()
     assert out.cpu().tolist() == [127, 255, 255, 0, 0, 0, 0, 255]
+
+
+def test_rank_frames_are_ordered_on_torchs_stream(earth):
+    """The multi-GPU path's stream order (raytracing_amd/distributed.py): each rank's frame is rendered on a side stream
+    and handed to torch's current stream by an event, so a consumer queued there -- the RCCL reduce in a real run, a
+    tensor sum here -- reads finished frames without any device-wide synchronisation.  Two ranks' frames rendered back to
+    back (same scene handle, same workspace) and summed at once must be the single-rank frame, byte for byte."""
+    import torch
+    from raytracing_amd.distributed import quantise, render_local
+    sc, co = _example("final_scene", earth)
+    cam = rt.Camera(co)
+    io = rt.ImageOptions(200, 200, 48, 50)
+    with pytest.raises(ValueError):
+        rt.RenderOptions(stream=torch.cuda.current_stream().cuda_stream).to_c()   # handle 0 cannot be named
+    for _ in range(2):
+        parts = [render_local(sc, cam, io, seed=7, rank=r, world_size=2) for r in range(2)]
+        total = parts[0] + parts[1]                        # queued on torch's stream right behind the renders
+        rgb = quantise(sc, total)
+        busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")   # the current stream stays busy
+        full = render_local(sc, cam, io, seed=7)
+        assert torch.equal(total, full) and busy.shape[0] == 2048
+        ref = sc.render(cam, io, rt.RenderOptions(seed=7))
+        assert np.array_equal(rgb.cpu().numpy(), ref)
 
 
 def test_pixels_split_over_device_contexts(earth):
