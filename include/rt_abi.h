@@ -240,6 +240,18 @@ rt_status rt_render(rt_scene* scene, const rt_camera* camera, const rt_image_opt
 rt_status rt_render_device(rt_scene* scene, const rt_camera* camera, const rt_image_options* image_options,
                            const rt_render_options* render_options, double* d_mean_out);
 
+/* rt_render_device for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  Same arguments, same bytes in d_mean_out; calls no hipMalloc / hipFree /
+ * hipHostMalloc and creates no events: its queues, hit records, sample values, per-pixel sums and counters live in one
+ * static device array of the library's image (about 38.5 MB on every GPU the library is loaded on, held until the
+ * process ends).  Limits, checked up front (RT_ERR_UNSUPPORTED beyond them): at most 262 144 pixels owned by this rank
+ * (512 x 512 on one rank) and max_reflections <= 254; passes hold at most 262 144 paths.  RT_RENDER_PROFILE is refused.
+ * All calls on one GPU share that GPU's array, whichever scene handle they use: calls that overlap on a GPU race (every
+ * call overwrites what it reads before reading it, so nothing needs clearing between calls).  Returns after the work is
+ * enqueued on the stream; the caller synchronises. */
+rt_status rt_render_device_noalloc(rt_scene* scene, const rt_camera* camera, const rt_image_options* image_options,
+                                   const rt_render_options* render_options, double* d_mean_out);
+
 /* The per-pixel quantisation of src/lib.rs:68-72 ("max(0).min(1).sqrt() * 255.999 as u8")
  * on a device buffer of n doubles -> n bytes (device), enqueued on `stream`. */
 rt_status rt_quantise_device(rt_scene* scene, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream);

@@ -111,6 +111,7 @@ HIP_SYMBOLS = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_image_options), C.POINTER(rt_render_options), C.c_void_p, C.c_void_p]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_image_options), C.POINTER(rt_render_options), C.c_void_p]),
+    "rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_image_options), C.POINTER(rt_render_options), C.c_void_p]),
     "rt_quantise_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rt_intersect_batch": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(rt_ray), C.c_uint64, C.c_float, C.c_float, C.c_uint64, C.c_void_p, C.POINTER(rt_hit)]),
     "rt_scatter_batch": (C.c_int, [C.c_void_p, C.POINTER(rt_hit), C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(rt_scatter)]),

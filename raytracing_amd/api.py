@@ -379,6 +379,12 @@ class Scene:
         io = image_options.to_c()
         _abi.check(self._hip.rt_render_device(self.device(), C.byref(camera.abi), C.byref(io), C.byref(ro), C.c_void_p(d_mean_ptr)))
 
+    def render_device_noalloc(self, camera: Camera, image_options: ImageOptions, render_options: RenderOptions, d_mean_ptr: int):
+        """rt_render_device_noalloc: the same render out of the library's static device workspace (no allocation; size limits apply)."""
+        ro = render_options.to_c()
+        io = image_options.to_c()
+        _abi.check(self._hip.rt_render_device_noalloc(self.device(), C.byref(camera.abi), C.byref(io), C.byref(ro), C.c_void_p(d_mean_ptr)))
+
     def quantise_device(self, d_mean_ptr: int, n: int, d_rgb_ptr: int, stream: Optional[int] = None):
         """rt_quantise_device on `stream` (a real stream handle; None = the library's own stream, see RenderOptions.to_c)."""
         if stream is not None and int(stream) == 0:

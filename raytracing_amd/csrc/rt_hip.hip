@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -528,6 +529,26 @@ struct rt_scene {
     std::vector<hipEvent_t> event_pool;
 };
 
+// ---- the workspace of rt_render_device_noalloc: one array per GPU, in the library's image, never allocated or freed.
+// Largest pass and frame share it can hold (the entry point rejects more):
+#define RT_STATIC_MAX_PATHS (1u << 18)   // paths per pass
+#define RT_STATIC_MAX_PIXELS (1u << 18)  // pixels this rank owns
+#define RT_STATIC_MAX_DEPTH 254u         // max_reflections (queue-length slots: depth + 2)
+constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t ST_QUEUE = align256((size_t)RT_STATIC_MAX_PATHS * sizeof(float4));
+constexpr size_t ST_OFF_HITS = 6 * ST_QUEUE;
+constexpr size_t ST_OFF_VALUES = ST_OFF_HITS + align256((size_t)RT_STATIC_MAX_PATHS * sizeof(uint2));
+constexpr size_t ST_OFF_ACCUM = ST_OFF_VALUES + ST_QUEUE;
+constexpr size_t ST_OFF_OWNED = ST_OFF_ACCUM + align256((size_t)RT_STATIC_MAX_PIXELS * 3 * sizeof(double));
+constexpr size_t ST_OFF_COUNTS = ST_OFF_OWNED + align256((size_t)RT_STATIC_MAX_PIXELS * sizeof(uint32_t));
+constexpr size_t ST_BYTES = ST_OFF_COUNTS + align256((size_t)2 * (RT_STATIC_MAX_DEPTH + 2) * sizeof(uint32_t));  // about 38.5 MB
+static __device__ __align__(256) unsigned char scratch[ST_BYTES];
+// `scratch` above is a host-side stand-in for the symbol, not an address: each GPU has its own copy at its own address,
+// looked up once per device (rt_scene_create, with that device current) and used from then on.
+#define RT_MAX_DEVICES 64
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+
 template <class T>
 static rt_status upload(rt_scene* sc, const T* src, size_t n, const T** dst) {
     *dst = nullptr;
@@ -624,6 +645,17 @@ static void free_workspace(rt_scene* sc) {
     sc->ws = Workspace{};
 }
 
+// This device's address of `scratch` (the device is current).
+static rt_status resolve_scratch(int device) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return RT_OK;  // (rt_render_device_noalloc then reports that the device has no array)
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return RT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    return RT_OK;
+}
+
 extern "C" {
 
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -712,6 +744,7 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
     }
+    if ((st = resolve_scratch(device)) != RT_OK) { rt_scene_destroy(sc); return st; }
     *out = sc;
     return RT_OK;
 }
@@ -742,6 +775,23 @@ static rt_status ensure_workspace(rt_scene* sc, uint64_t n_paths, uint64_t n_pix
     HIP_TRY(hipHostMalloc((void**)&sc->h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
     w.paths = n_paths; w.pixels = n_pixels; w.n_counts = n_counts;
     return RT_OK;
+}
+
+// The same layout inside this device's `scratch` array.
+static Workspace static_workspace(unsigned char* base) {
+    Workspace w;
+    w.paths = RT_STATIC_MAX_PATHS; w.pixels = RT_STATIC_MAX_PIXELS; w.n_counts = RT_STATIC_MAX_DEPTH + 2;
+    for (int k = 0; k < 2; ++k) {
+        w.q[k].od0 = reinterpret_cast<float4*>(base + (3 * k + 0) * ST_QUEUE);
+        w.q[k].od1 = reinterpret_cast<float4*>(base + (3 * k + 1) * ST_QUEUE);
+        w.q[k].thr = reinterpret_cast<float4*>(base + (3 * k + 2) * ST_QUEUE);
+    }
+    w.hits = reinterpret_cast<uint2*>(base + ST_OFF_HITS);
+    w.values = reinterpret_cast<float4*>(base + ST_OFF_VALUES);
+    w.accum = reinterpret_cast<double*>(base + ST_OFF_ACCUM);
+    w.owned = reinterpret_cast<uint32_t*>(base + ST_OFF_OWNED);
+    w.counts = reinterpret_cast<uint32_t*>(base + ST_OFF_COUNTS);
+    return w;
 }
 
 namespace {
@@ -1022,6 +1072,14 @@ extern "C" {
 
 rt_status rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out) {
     return render_impl(sc, cam, io, ro, d_mean_out, false, nullptr);
+}
+
+rt_status rt_render_device_noalloc(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out) {
+    if (!sc) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    unsigned char* base = (sc->device >= 0 && sc->device < RT_MAX_DEVICES) ? g_scratch_ptr[sc->device] : nullptr;
+    if (!base) return fail(RT_ERR_UNSUPPORTED, "this device has no static workspace (device index beyond the library's table)");
+    const Workspace ws = static_workspace(base);
+    return render_impl(sc, cam, io, ro, d_mean_out, false, &ws);
 }
 
 rt_status rt_quantise_device(rt_scene* sc, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream) {
