@@ -156,7 +156,12 @@ RT_HD void axis_perm(uint32_t axis, int& p1, int& p2, int& o) {  // shape.rs:138
 // for grazing rays), so wrapped primitives take the same code in f64 (sin/cos and offsets are kept in
 // f64 in rt_xform), as spheres always do.
 RT_HD double compd(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
-RT_HD D3 ray_at(D3 o, D3 d, double t) { return (t <= 0.0) ? o : d3(fma(d.x, t, o.x), fma(d.y, t, o.y), fma(d.z, t, o.z)); }
+// (f64: the product and the sum rounded one after the other, as the reference's `origin + direction * t` is, geometry.rs:345.
+// The sign of the few-ulp residue a hit point keeps off its plane is observable: a ray leaving the floor under a medium
+// whose boundary box stands on it starts inside the box for a residue >= 0 and outside for < 0, and only then does the
+// medium act on it (shape.rs:386-410).  Unfused, the residue is exactly 0 more often than not, as in the reference; a
+// fused multiply-add leaves it non-zero, half of the time negative, and darkens cornell_smoke's floor by up to 14 %.)
+RT_HD D3 ray_at(D3 o, D3 d, double t) { return (t <= 0.0) ? o : d3(d.x * t + o.x, d.y * t + o.y, d.z * t + o.z); }
 RT_HD D3 rotate_cs(D3 s, uint32_t kind, double c, double sn) {
     D3 o = s;
     if (kind == RT_XF_ROTATE_X) { o.y = s.y * c - s.z * sn; o.z = s.y * sn + s.z * c; }

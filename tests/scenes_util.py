@@ -4,9 +4,10 @@ import numpy as np
 import raytracing_amd as rt
 
 EXAMPLES = ["random_spheres", "cornell", "perlin", "cornell_smoke", "final_scene"]
-# Hit-record tolerance: |got - oracle| <= TOL * max(1, |oracle|) on t, normal, in_vec, u, v.  The point is
-# origin + t * direction with t held in fp32, so its error scales with the ray, not with the coordinate it
-# lands on: |got - oracle| <= TOL * max(1, |oracle point|_inf, |ray origin|_inf).
+# Hit-record tolerance.  t: purely relative, |got - oracle| <= TOL * |oracle|.  normal, in_vec (unit vectors) and u, v
+# (in [0, 1]): |got - oracle| <= TOL * max(1, |oracle|), i.e. relative to their range.  The point is origin + t * direction
+# with t held in fp32, so its error scales with the ray, not with the coordinate it lands on:
+# |got - oracle| <= TOL * max(1, |oracle point|_inf, |ray origin|_inf).
 TOL = 1e-5
 
 
@@ -98,6 +99,8 @@ def compare_hits(got, ref, what="", tol=TOL, allow_flag_mismatch=0.0, allow_prim
     for f in ("t", "point", "normal", "in_vec", "u", "v"):
         a, b = got[f][same].astype(np.float64), ref[f][same]
         scale = np.maximum(1.0, np.abs(b))
+        if f == "t":
+            scale = np.maximum(np.abs(b), 1e-300)
         if f == "point":   # relative to the largest finite coordinate (a point may have NaN or infinite components on both sides)
             fin = lambda x: np.where(np.isfinite(x), np.abs(x), 0.0).max(axis=1, keepdims=True)
             scale = np.maximum(1.0, fin(b))

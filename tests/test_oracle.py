@@ -329,3 +329,22 @@ def test_against_committed_fixtures(earth):
         rgb, mean, _, _ = sc.render(co, g["w"], g["h"], g["spp"], 50, seed=1, threads=4)
         assert np.allclose(mean.mean(axis=(0, 1)), g["mean_rgb"], rtol=1e-9)
         assert int(rgb.astype(np.uint64).sum()) == g["rgb_sum"]
+
+
+def test_converged_fixtures_are_what_the_oracle_renders(earth):
+    """tests/golden/converged_<scene>.npz (4 096-spp frames of two seeds, made by tests/golden/make_converged.py): one row of
+    each frame re-rendered here must be the stored numbers, so a fixture cannot outlive a change of the oracle; and the two
+    seeds' frames must differ by noise only (their 8 x 8 block means agree far better than their pixels)."""
+    for name in ("cornell", "perlin", "cornell_smoke", "final_scene"):
+        fx = np.load(os.path.join(GOLDEN, f"converged_{name}.npz"))
+        w, h, spp, depth = (int(fx[k]) for k in ("width", "height", "spp", "depth"))
+        assert spp >= 4096 and depth == 50
+        sc, co = OracleScene.example(name, int(fx["scene_seed"]), earth if name == "final_scene" else None)
+        row = h // 2
+        for key, seed in (("mean_a", int(fx["seed_a"])), ("mean_b", int(fx["seed_b"]))):
+            got = sc.render(co, w, h, spp, depth, seed=seed, threads=8, rows=(row, row + 1))[1]
+            assert np.allclose(got[row], fx[key][row], rtol=1e-12, atol=1e-15, equal_nan=True), (name, key)
+        a, b = np.clip(fx["mean_a"], 0, 1), np.clip(fx["mean_b"], 0, 1)
+        blocks = lambda x: x[:h // 8 * 8, :w // 8 * 8].reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+        pix, blk = np.sqrt(((a - b) ** 2).mean()), np.sqrt(((blocks(a) - blocks(b)) ** 2).mean())
+        assert 0 < blk < 0.25 * pix, (name, pix, blk)
