@@ -204,9 +204,12 @@ typedef struct rt_render_options {
     uint32_t tile_w, tile_h;  /* 0 = default 16 x 16 */
     uint32_t samples_per_pass;/* 0 = automatic; does not change the result */
     uint32_t flags;           /* RT_RENDER_* */
-    void* stream;             /* hipStream_t to launch on; NULL = the library's own (non-blocking) stream, which has no
-                                 order with the null stream or any other: a caller that works on the legacy default
-                                 stream passes a stream of its own and orders the two with events */
+    void* stream;             /* hipStream_t the render is ordered with: it starts after the work queued there so far, and
+                                 work queued there afterwards starts after the frame is complete (the kernels themselves run
+                                 on the library's own streams).  NULL = no ordering with any caller stream: the render runs on
+                                 the library's own (non-blocking) streams alone, the null stream included in "no ordering";
+                                 a caller that works on the legacy default stream, whose handle is also 0, passes a stream of
+                                 its own and orders the two with events */
 } rt_render_options;
 enum {
     RT_RENDER_PROFILE = 1u,  /* time every kernel launch with HIP events (rt_get_profile) */

@@ -518,6 +518,7 @@ struct rt_scene {
     std::vector<void*> allocs;
     hipStream_t own_stream = nullptr, side_stream[RT_MAX_PARTS - 1] = {};  // side streams: the other parts of a pass (see render_impl)
     hipEvent_t ev_fork = nullptr, ev_join[RT_MAX_PARTS - 1] = {};
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;  // order a caller's stream with the library's own (render_impl)
     bool nodes_fit_lds = false;
     Workspace ws;
     uint32_t* h_counts = nullptr;  // pinned
@@ -675,6 +676,8 @@ void rt_scene_destroy(rt_scene* sc) {
     if (sc->own_stream) (void)hipStreamDestroy(sc->own_stream);
     for (auto& x : sc->side_stream) if (x) (void)hipStreamDestroy(x);
     if (sc->ev_fork) (void)hipEventDestroy(sc->ev_fork);
+    if (sc->ev_in) (void)hipEventDestroy(sc->ev_in);
+    if (sc->ev_out) (void)hipEventDestroy(sc->ev_out);
     for (auto& x : sc->ev_join) if (x) (void)hipEventDestroy(x);
     delete sc;
 }
@@ -728,6 +731,8 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     for (auto& x : sc->side_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming);
     for (auto& x : sc->ev_join) if (e == hipSuccess) e = hipEventCreateWithFlags(&x, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->ev_out, hipEventDisableTiming);
     if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("stream / event creation: ") + hipGetErrorString(e)); }
     // The node array goes to LDS when it fits beside the workgroup's ray counter (160 KB per CU, one 1024-thread workgroup
     // per CU): the walk kernels then take the start of their dynamic LDS for address 0 (walk_step_flat).
@@ -862,7 +867,23 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     if (st != RT_OK) return st;
     if (!d_mean_out) return fail(RT_ERR_INVALID_ARGUMENT, "output buffer is null");
     HIP_TRY(hipSetDevice(sc->device));
-    hipStream_t stream = ro->stream ? (hipStream_t)ro->stream : sc->own_stream;
+    // The work always runs on the library's own streams; a caller's stream only orders it: the render starts after what the
+    // caller has queued there and the caller's stream continues after the frame is complete.  (The two halves of a pass
+    // overlap only if their streams sit on different hardware queues, which the library's two streams, created one after
+    // the other, do; run on a stream made elsewhere, final_scene lost 13 % to serialisation.)
+    hipStream_t caller = ro->stream ? (hipStream_t)ro->stream : nullptr;
+    hipStream_t stream = sc->own_stream;
+    if (caller) {
+        HIP_TRY(hipEventRecord(sc->ev_in, caller));
+        HIP_TRY(hipStreamWaitEvent(stream, sc->ev_in, 0));
+    }
+    auto hand_back = [&]() -> rt_status {
+        if (caller) {
+            HIP_TRY(hipEventRecord(sc->ev_out, stream));
+            HIP_TRY(hipStreamWaitEvent(caller, sc->ev_out, 0));
+        }
+        return RT_OK;
+    };
     const bool profile = (ro->flags & RT_RENDER_PROFILE) != 0;
     if (fixed && profile) return fail(RT_ERR_INVALID_ARGUMENT, "RT_RENDER_PROFILE creates events: not available without allocation");
     const uint32_t W = io->width, H = io->height;
@@ -884,7 +905,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     std::memset(&sc->prof, 0, sizeof(sc->prof));
     for (auto& e : sc->events) { sc->event_pool.push_back(e.second.first); sc->event_pool.push_back(e.second.second); }  // left by a call that failed
     sc->events.clear();
-    if (n_owned == 0) { if (sync_at_end) HIP_TRY(hipStreamSynchronize(stream)); return RT_OK; }
+    if (n_owned == 0) { if (sync_at_end) HIP_TRY(hipStreamSynchronize(stream)); return hand_back(); }
 
     // Samples per pass: large passes amortise what every launch costs (the workgroups' copy of the node array into LDS,
     // the launch itself, the ragged end of a persistent kernel): 64 M paths a pass (120 bytes of workspace each) run
@@ -1065,7 +1086,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         HIP_TRY(hipStreamSynchronize(stream));
         if (profile && (st = collect_profile(sc)) != RT_OK) return st;
     }
-    return RT_OK;
+    return hand_back();
 }
 
 extern "C" {
