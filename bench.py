@@ -179,11 +179,12 @@ def main():
             trav, shade, raygen = algorithmic_flops(cnt)
             launches = max(prof["traverse_launches"], 1)
             seg_per_launch = prof["traverse_segments"] / launches
-            common = {"segments_per_launch": round(seg_per_launch), "profile_spp": prof_spp,
+            common = {"profile_spp": prof_spp,
                       "flops_per_sample_all_kernels": round((trav + shade + raygen) / cnt["samples"], 1),
                       "segments_per_sample": round(cnt["segments"] / cnt["samples"], 2),
                       "kernel_ms": {k: round(prof[k + "_ms"], 2) for k in _abi.RT_K_NAMES}}
-            if prof["traverse_ms"] >= prof["shade_ms"]:
+            fused = prof["traverse_launches"] == 0  # a handful of leaves: one kernel per bounce walks and shades (no hit records)
+            if not fused and prof["traverse_ms"] >= prof["shade_ms"]:
                 trav_per_seg = trav / cnt["segments"]
                 ms_per_launch = prof["traverse_ms"] / launches
                 achieved = trav_per_seg * seg_per_launch / (ms_per_launch * 1e-3) / 1e12
@@ -195,15 +196,19 @@ def main():
             else:
                 # every path ends exactly once, all but a sliver of them in a shading launch: dead = paths, alive = segments - paths
                 paths, segs = prof["samples"], prof["traverse_segments"]
-                bytes_per_seg = SHADE_BYTES_IN + (SHADE_BYTES_OUT_ALIVE * max(segs - paths, 0) + SHADE_BYTES_OUT_DEAD * min(paths, segs)) / max(segs, 1)
+                seg_per_launch = segs / max(prof["shade_launches"], 1)
+                bytes_per_seg = SHADE_BYTES_IN - (8 if fused else 0) + (SHADE_BYTES_OUT_ALIVE * max(segs - paths, 0) + SHADE_BYTES_OUT_DEAD * min(paths, segs)) / max(segs, 1)
                 ms_per_launch = prof["shade_ms"] / max(prof["shade_launches"], 1)
                 achieved = bytes_per_seg * seg_per_launch / (ms_per_launch * 1e-3) / 1e9
                 pmc = pmc_counters(args.config, "k_shade")
-                roofline = {"bound": "hbm", "kernel": "k_shade", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                flops_per_seg = (trav + shade) / cnt["segments"] if fused else shade / cnt["segments"]
+                roofline = {"bound": "hbm", "kernel": "k_shade<SHADE_SCAN> (walk + shade)" if fused else "k_shade", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                             "frac": round(achieved / PEAK_HBM_GBPS, 4),
                             "traffic": round(pmc["hbm_bytes_per_segment"] * seg_per_launch) if pmc and "hbm_bytes_per_segment" in pmc else None,
-                            "bytes_per_segment": round(bytes_per_seg, 1), "ms_per_launch": round(ms_per_launch, 4), "counters": pmc}
+                            "bytes_per_segment": round(bytes_per_seg, 1), "ms_per_launch": round(ms_per_launch, 4),
+                            "valu_frac": round(flops_per_seg * seg_per_launch / (ms_per_launch * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4), "counters": pmc}
             roofline.update(common)
+            roofline["segments_per_launch"] = round(seg_per_launch)
         result = {"metric": f"Msamples/sec (whole node) on {args.config}", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world,
                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

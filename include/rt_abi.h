@@ -217,6 +217,8 @@ enum {
     RT_RENDER_TAIL_ONLY = 4u, /* every path runs start to end in the tail kernel (same image; for tests) */
     RT_RENDER_NODES_IN_GLOBAL = 8u, /* walk the BVH in global memory even when it would fit in LDS (same image; for tests) */
     RT_RENDER_ONE_STREAM = 16u, /* never split a pass into two halves on two streams (same image; for tests and clean kernel timings) */
+    RT_RENDER_ONE_KERNEL = 64u,  /* walk and shade a bounce in one kernel whatever the tree's size (same image; for tests) */
+    RT_RENDER_TWO_KERNELS = 128u,/* never do that: every bounce as a traversal launch and a shading launch (same image; for tests) */
     RT_RENDER_RECALIBRATE = 32u /* measure the frame's schedule again (where the tail kernel takes over, whether two streams
                                    pay) instead of reusing what an earlier frame of the same shape on this handle learnt */
 };

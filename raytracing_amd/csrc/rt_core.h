@@ -119,6 +119,9 @@ struct SceneView {
     const uint8_t* perm; const struct WalkNode* bvh;  // bvh: n_bvh_nodes slots and one sentinel slot (make_walk_nodes)
     uint32_t n_prims, n_bvh_nodes;
     float background[3];
+    // array lengths, for the kernels that copy a small scene's tables into LDS (texels stay in global memory)
+    uint32_t n_spheres, n_rects, n_boxes, n_xforms, n_textures, n_images, n_perm_tables;
+    uint32_t lds_scene_bytes;  // bytes those tables take in LDS behind the node array (each 16-byte aligned); 0 = leave them in global memory
 };
 
 // Rectangles and boxes as the kernels hold them: every f64 coordinate of the description as an fp32 value `hi` and an
@@ -228,6 +231,14 @@ RT_HD double rsqrt_near(double x) {  // 1 / sqrt(x) for positive finite x
     r = fma(-x * z, z, 1.0);
     return fma(z * r, 0.5, z);
 }
+// 1 / x in f64 for any x: the refinement of rcp_near turns an infinite estimate into NaN (0 * inf), so zeros and
+// infinities keep the hardware's own answer (+-inf, +-0), which is the quotient's.
+RT_HD double rcp_exact_at_zero(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double r = fma(fma(-x, r0, 1.0), r0, r0);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return (r - r == 0.0) ? r : r0;  // (finite: the refined value; else the estimate)
+}
 // 1 / direction for the walk (the hardware reciprocal, within an ulp; the walk's node boxes are widened by far more, and the
 // exact leaf tests of one ray all use the same value)
 RT_HD V3 ray_inv(V3 d) { return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
@@ -237,6 +248,7 @@ RT_HD void sincos_turns(float u, float& s, float& c) { sincospif(2.0f * u, &s, &
 RT_HD double sqrt_near(double x) { return sqrt(x); }
 RT_HD double rcp_near(double x) { return 1.0 / x; }
 RT_HD double rsqrt_near(double x) { return 1.0 / sqrt(x); }
+RT_HD double rcp_exact_at_zero(double x) { return 1.0 / x; }
 RT_HD V3 ray_inv(V3 d) { return v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 RT_HD void sincos_turns(float u, float& s, float& c) { const float phi = (2.0f * RT_PI_F) * u; s = sinf(phi); c = cosf(phi); }
 #endif
@@ -353,6 +365,29 @@ RT_HD bool box_t<float, V3>(const DevBox& B, V3 o, V3 d, float tmin, float tmax,
     float q[6];
     box_quotients(B, o, inv, q);
     return box_sides_q(B, o, d, q, tmin, tmax, t_out, side);
+}
+
+// The f64 form (boxes behind Translated / Rotated wrappers, boundaries of media): the same six sides with the plane parameters
+// formed as (bound - origin) * (1 / direction), the three reciprocals refined to within an ulp or two (rcp_near).  The
+// reference divides (shape.rs:321); the product differs from the quotient by a couple of f64 ulps, nine orders of magnitude
+// below the fp32 rounding of the accepted t, and goes to +-inf / NaN for a zero direction component exactly as the quotient
+// does.  Six f64 divisions were two thirds of the instructions of this test.
+template <>
+RT_HD bool box_t<double, D3>(const DevBox& B, D3 o, D3 d, double tmin, double tmax, double& t_out, int& side) {
+    const D3 inv = d3(rcp_exact_at_zero(d.x), rcp_exact_at_zero(d.y), rcp_exact_at_zero(d.z));
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        uint32_t axis; double x0, y0, x1, y1, h, h_lo;
+        box_side<double>(B, k, axis, x0, y0, x1, y1, h, h_lo);
+        int p1, p2, oo; axis_perm(axis, p1, p2, oo);
+        const double t = (h - compd(o, oo)) * compd(inv, oo);
+        const D3 pt = ray_at(o, d, t);
+        const double a = compd(pt, p1), b = compd(pt, p2);
+        const bool ok = !(t < tmin || t > tmax) && !(a < x0 || a > x1 || b < y0 || b > y1);
+        tmax = ok ? t : tmax; t_out = ok ? t : t_out; side = ok ? k : side; any = any || ok;
+    }
+    return any;
 }
 
 // Ray parameter of the innermost shape for a ray already in its frame.

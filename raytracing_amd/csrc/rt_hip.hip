@@ -144,14 +144,44 @@ __global__ void __launch_bounds__(1024) k_owned_list(uint32_t W, uint32_t H, uin
 #define RT_TRAV_BS 1024
 #define RT_LDS_NODE_LIMIT (144u * 1024u)  // dynamic LDS the walk kernels may ask for
 #define RT_LDS_BEHIND_NODES 16u           // k_traverse keeps its ray counter behind the node array
+#define RT_LDS_SCENE_LIMIT (16u * 1024u)  // a scene whose tables (primitives, geometry, materials, textures, noise tables) fit in this goes to LDS whole
+// A small scene's tables follow the node array into LDS (S.lds_scene_bytes != 0, set by the host when they fit): the general
+// primitive test reads a primitive, its wrappers and its geometry one after the other, shading reads the material and the
+// texture, Perlin noise makes 24 dependent look-ups in its permutation table -- chains of dependent loads that cost a trip
+// to the L2 each from global memory and a fraction of that from LDS (the pointers in the SceneView are generic addresses;
+// pointed into LDS the same code reads them with flat loads).
+__device__ __forceinline__ uint32_t lds_align16(uint32_t bytes) { return (bytes + 15u) & ~15u; }
+template <class T>
+__device__ __forceinline__ const T* stage_table(const T* src, uint32_t count, unsigned char*& at) {
+    const uint32_t words = (uint32_t)(sizeof(T) / 4u) * count;  // every table's element size is a multiple of four bytes
+    static_assert(sizeof(T) % 4 == 0, "table element size");
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(at);
+    for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) d[k] = s[k];
+    const T* out = reinterpret_cast<const T*>(at);
+    at += lds_align16(words * 4u);
+    return count ? out : src;
+}
 template <bool NODES_IN_LDS>
 __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds) {
     SceneView V = S;
     if (NODES_IN_LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(S.bvh);
         for (uint32_t k = threadIdx.x; k < 2u * (S.n_bvh_nodes + 1u); k += blockDim.x) lds[k] = src[k];  // with the sentinel slot
-        __syncthreads();
         V.bvh = reinterpret_cast<const WalkNode*>(lds);
+        if (S.lds_scene_bytes) {
+            unsigned char* at = reinterpret_cast<unsigned char*>(lds + 2u * (S.n_bvh_nodes + 1u) + 1u);  // (one 16-byte slot behind the nodes is k_traverse's ray counter)
+            V.prims = stage_table(S.prims, S.n_prims, at);
+            V.spheres = stage_table(S.spheres, S.n_spheres, at);
+            V.rects = stage_table(S.rects, S.n_rects, at);
+            V.boxes = stage_table(S.boxes, S.n_boxes, at);
+            V.xforms = stage_table(S.xforms, S.n_xforms, at);
+            V.shade = stage_table(S.shade, S.n_prims, at);
+            V.textures = stage_table(S.textures, S.n_textures, at);
+            V.images = stage_table(S.images, S.n_images, at);
+            V.perm = reinterpret_cast<const uint8_t*>(stage_table(reinterpret_cast<const uint32_t*>(S.perm), 64u * S.n_perm_tables, at));
+        }
+        __syncthreads();
     }
     return V;
 }
@@ -314,31 +344,101 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 // Register budgets: k_traverse is held to 80 VGPRs (4 waves per SIMD = 320 of the 512 registers of a lane) and k_shade
 // to 96, so that one shading workgroup (2 waves per SIMD) fits beside the traversal workgroup of the pass's other half.
 #define RT_SHADE_BS 512
-__global__ void __launch_bounds__(RT_SHADE_BS, 5) k_shade(SceneView S, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+#define RT_SCAN_MAX_LEAVES 16u   // leaves up to which a bounce runs as one kernel that scans them
+// How k_shade gets a ray's closest hit:
+//   SHADE_HITS  from the hit records of a k_traverse launch;
+//   SHADE_WALK  by walking the tree itself (closest_hit() of rt_core.h, every lane its own walk, node array staged into LDS);
+//   SHADE_SCAN  by trying the leaves one after the other, all lanes of the wave at the same leaf (closest_hit_scan below).
+// For trees of a handful of leaves (the Cornell rooms, the perlin scene) a walk is a few steps, and one launch per bounce
+// that reads a ray once and writes its successor moves 96 bytes per segment where the two-kernel form moves 147 and pays
+// two launches.  Same arithmetic, same bytes in the image.
+enum { SHADE_HITS = 0, SHADE_WALK = 1, SHADE_SCAN = 2 };
+
+// The closest hit for a tree of a few leaves: the wave goes through the leaves in their order, every lane testing the same
+// leaf at the same time.  That is BvhNode::scatter_ (lib.rs:228-257) without the inner nodes, which only cull: a leaf is tried
+// iff the ray meets the leaf's own box within (tmin, current tmax), and a ray that does has met every box around it (they
+// contain it, and the slab test is monotone in the bounds), so the same leaves are tried in the same order against the same
+// bounds as in closest_hit().  The kind of the leaf is the same for all lanes, so its test is straight code for the wave
+// instead of each lane's own branch, and a scene of eight objects costs eight box tests and the tests of the leaves some lane
+// enters, not a persistent kernel's turns.  `live`: lanes without a ray go through the motions with every test masked off.
+__device__ __forceinline__ bool closest_hit_scan(const SceneView& S, const Ray& r, bool live, float tmin, const DrawKey& key, float& best_t, uint32_t& best_prim,
+                                                 int& best_side) {
+    const bool ok = live && !has_negative_zero(r.d);
+    const V3 inv_c = walk_cap(ray_inv(r.d));
+    const V3 oi = v3(r.o.x * inv_c.x, r.o.y * inv_c.y, r.o.z * inv_c.z);
+    Walk w; walk_init(w, RT_INF_F);
+    const uint32_t n = S.n_bvh_nodes * RT_NODE_STRIDE;
+    for (uint32_t pos = 0; pos < n;) {  // (the same position in every lane)
+        const WalkNode& N = node_at(S.bvh, pos);
+        const uint32_t leaf = __builtin_amdgcn_readfirstlane(N.prim);
+        if (leaf < RT_NODE_LEAF) { pos += RT_NODE_STRIDE; continue; }  // an inner node: on to its first child
+        const uint32_t skip = __builtin_amdgcn_readfirstlane(N.skip);
+        const bool pass = ok && node_hit(N, inv_c, oi, tmin, fminf(w.tmax, RT_WALK_FAR));
+        if (__ballot(pass) != 0ull && pass) {
+            w.leaf_node = pos;
+            if (!walk_leaf_fast(S, r, inv_c, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, key, leaf, w);
+        }
+        pos = skip;  // a leaf's skip link also jumps over its payload slots
+    }
+    best_t = w.t; best_prim = w.prim; best_side = w.side;
+    return w.found;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
+    extern __shared__ uint4 lds_nodes[];
     __shared__ uint32_t wave_cnt[2][RT_SHADE_BS / 64];
     __shared__ uint32_t block_base[2];
+    const SceneView S = stage_nodes<MODE != SHADE_HITS>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t base = blockIdx.x * RT_SHADE_BS; base < count; base += gridDim.x * RT_SHADE_BS) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false, to_front = false;
         Ray r; V3 thr; uint32_t path = 0, pixel = 0;
-        if (i < count) {
+        if (MODE == SHADE_SCAN) {
+            // the scan is the wave's, so the hit is found outside the per-lane branch below
+            DrawKey key = make_key(P, 0u, 0u, bounce);
+            r.o = v3(0.0f, 0.0f, 0.0f); r.d = v3(1.0f, 1.0f, 1.0f); r.time = 0.0f; thr = v3(0.0f, 0.0f, 0.0f);
+            const bool live = i < count;
+            if (live) {
+                const uint32_t at = queue_slot(i, n_front, P.n_paths);
+                const NtF4 a = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od0[at])), b = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od1[at])),
+                           c = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.thr[at]));
+                r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
+                path = __float_as_uint(b.w);
+                thr = v3(c.x, c.y, c.z);
+                pixel = __float_as_uint(c.w);
+                key = make_key(P, path, pixel, bounce);
+            }
+            float t = 0.0f; uint32_t prim = 0; int side = 0;
+            const bool hit = closest_hit_scan(S, r, live, 0.001f, key, t, prim, side);  // lib.rs:90: (0.001, inf)
+            if (live) {
+                V3 value;
+                alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value);
+                if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
+                else to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
+            }
+        } else if (i < count) {
             const uint32_t at = queue_slot(i, n_front, P.n_paths);
             const NtF4 a_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od0[at])), b_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od1[at])),
                        c_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.thr[at]));
-            const NtU2 h_ = __builtin_nontemporal_load(reinterpret_cast<const NtU2*>(&hits[at]));
             float4 a = make_float4(a_.x, a_.y, a_.z, a_.w), b = make_float4(b_.x, b_.y, b_.z, b_.w), c = make_float4(c_.x, c_.y, c_.z, c_.w);
-            uint2 hh = make_uint2(h_.x, h_.y);
             r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y); r.time = b.z;
             path = __float_as_uint(b.w);
             thr = v3(c.x, c.y, c.z);
             pixel = __float_as_uint(c.w);
             DrawKey key = make_key(P, path, pixel, bounce);
             V3 value;
-            bool hit = hh.y != RT_HIT_NONE;
-            alive = shade_step(S, r, thr, key, hit, __uint_as_float(hh.x), hh.y & 0x1FFFFFFFu, (int)(hh.y >> 29), bounce + 1 >= P.max_depth, value);
+            bool hit; float t = 0.0f; uint32_t prim = 0; int side = 0;
+            if (MODE == SHADE_WALK) {
+                hit = closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);  // lib.rs:90: (0.001, inf)
+            } else {
+                const NtU2 h_ = __builtin_nontemporal_load(reinterpret_cast<const NtU2*>(&hits[at]));
+                hit = h_.y != RT_HIT_NONE; t = __uint_as_float(h_.x); prim = h_.y & 0x1FFFFFFFu; side = (int)(h_.y >> 29);
+            }
+            alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value);
             if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
             else to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
         }
@@ -514,6 +614,7 @@ struct Calibration { uint32_t width, height, depth, n_owned; int tail_from; bool
 struct rt_scene {
     int device = 0;
     uint32_t n_cu = 0;
+    uint32_t n_leaves = 0;  // leaves of the tree (primitives that can be hit)
     SceneView view{};
     std::vector<void*> allocs;
     hipStream_t own_stream = nullptr, side_stream[RT_MAX_PARTS - 1] = {};  // side streams: the other parts of a pass (see render_impl)
@@ -725,7 +826,11 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         V.n_bvh_nodes = (uint32_t)nodes.size() - 1;
     }
 #undef UP
+    for (uint32_t i = 0; i < D->n_bvh_nodes; ++i) sc->n_leaves += D->bvh[i].prim != RT_BVH_NONE;
     V.n_prims = D->n_prims;
+    V.n_spheres = D->n_spheres; V.n_rects = D->n_rects; V.n_boxes = D->n_boxes; V.n_xforms = D->n_xforms;
+    V.n_textures = D->n_textures; V.n_images = D->n_images; V.n_perm_tables = D->n_perm_tables;
+    V.lds_scene_bytes = 0;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
     for (auto& x : sc->side_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
@@ -741,12 +846,21 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     sc->n_cu = (uint32_t)prop.multiProcessorCount;
     const size_t node_bytes = ((size_t)V.n_bvh_nodes + 1) * sizeof(WalkNode);
     sc->nodes_fit_lds = V.n_bvh_nodes > 0 && node_bytes + RT_LDS_BEHIND_NODES <= RT_LDS_NODE_LIMIT;
+    {   // a small scene's tables go to LDS with the nodes (stage_nodes): sized exactly as stage_table lays them out
+        auto a16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t tables = a16(sizeof(rt_prim) * D->n_prims) + a16(sizeof(rt_sphere) * D->n_spheres) + a16(sizeof(DevRect) * D->n_rects) +
+                              a16(sizeof(DevBox) * D->n_boxes) + a16(sizeof(rt_xform) * D->n_xforms) + a16(sizeof(ShadeRec) * D->n_prims) +
+                              a16(sizeof(rt_texture) * D->n_textures) + a16(sizeof(rt_image) * D->n_images) + a16(256u * (size_t)D->n_perm_tables);
+        if (sc->nodes_fit_lds && tables <= RT_LDS_SCENE_LIMIT && node_bytes + RT_LDS_BEHIND_NODES + tables <= RT_LDS_NODE_LIMIT) V.lds_scene_bytes = (uint32_t)tables;
+    }
     if (sc->nodes_fit_lds) {
         hipFuncAttributes fa;
         e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_traverse<true>));
         if (e == hipSuccess && fa.sharedSizeBytes != 0) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array"); }
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade<SHADE_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade<SHADE_SCAN>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
     }
     if ((st = resolve_scratch(device)) != RT_OK) { rt_scene_destroy(sc); return st; }
@@ -930,6 +1044,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const uint32_t max_grid = sc->n_cu * 8u;
     const size_t node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
     const bool nodes_in_lds = sc->nodes_fit_lds && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
+    const size_t lds_bytes = node_bytes + RT_LDS_BEHIND_NODES + sc->view.lds_scene_bytes;  // dynamic LDS of the kernels that stage the nodes
     const uint32_t tail_threshold = sc->n_cu * 512u;
     Launcher L{sc, stream, profile};
     hipEvent_t ev;
@@ -944,6 +1059,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     P.up_sign = cam->v[P.up_axis] < 0.0 ? -1.0f : 1.0f;
 
     const bool force_wavefront = (ro->flags & RT_RENDER_NO_TAIL) != 0, force_tail = (ro->flags & RT_RENDER_TAIL_ONLY) != 0;
+    // one kernel per bounce (k_shade<true>: walk and shade) for trees of a few dozen node slots that fit in LDS
+    const bool scan = sc->n_leaves <= RT_SCAN_MAX_LEAVES;
+    const bool fused = nodes_in_lds && !(ro->flags & RT_RENDER_TWO_KERNELS) && ((ro->flags & RT_RENDER_ONE_KERNEL) || scan);
     int tail_from = force_tail ? 0 : -1;  // bounce at which k_tail takes over; -1 = not calibrated yet
     bool split_pays = false;               // set by the calibrating pass: traversal dominates shading
     Calibration* known = nullptr;
@@ -966,13 +1084,13 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     };
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
-            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes + RT_LDS_BEHIND_NODES, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
         else
             hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), RT_LDS_BEHIND_NODES, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
     };
     auto launch_tail = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
-            hipLaunchKernelGGL(k_tail<true>, dim3(trav_grid), dim3(RT_TRAV_BS), node_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values,
+            hipLaunchKernelGGL(k_tail<true>, dim3(trav_grid), dim3(RT_TRAV_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values,
                                h.counts + depth + 1, b);
         else
             hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(RT_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values, h.counts + depth + 1, b);
@@ -1021,12 +1139,21 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             if (tail_from >= 0 && !force_wavefront && (int)b >= tail_from) break;
             for (int k = 0; k < n_halves; ++k) {  // (event timing only in one-half passes: L works on `stream`)
                 Half& h = half[k];
-                if (n_halves == 1 && (st = L.begin(RT_K_TRAVERSE, &ev)) != RT_OK) return st;
-                launch_traverse(h, b, grid[k], trav_grid[k]);
-                if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
+                if (!fused) {
+                    if (n_halves == 1 && (st = L.begin(RT_K_TRAVERSE, &ev)) != RT_OK) return st;
+                    launch_traverse(h, b, grid[k], trav_grid[k]);
+                    if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
+                }
                 if (n_halves == 1 && (st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
-                hipLaunchKernelGGL(k_shade, dim3(shade_grid[k]), dim3(RT_SHADE_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b,
-                                   h.counts + b + 1, h.values, b);
+                if (fused && scan)
+                    hipLaunchKernelGGL(k_shade<SHADE_SCAN>, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
+                                       h.counts + b, h.counts + b + 1, h.values, b);
+                else if (fused)
+                    hipLaunchKernelGGL(k_shade<SHADE_WALK>, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
+                                       h.counts + b, h.counts + b + 1, h.values, b);
+                else
+                    hipLaunchKernelGGL(k_shade<SHADE_HITS>, dim3(shade_grid[k]), dim3(RT_SHADE_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
+                                       h.counts + b, h.counts + b + 1, h.values, b);
                 if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
                 h.cur ^= 1;
             }

@@ -184,7 +184,7 @@ def test_a_tree_too_large_for_lds():
     cam = rt.Camera(co)
     io = rt.ImageOptions(64, 64, 16, 12)
     _, base = sc.render(cam, io, rt.RenderOptions(seed=2), want_mean=True)
-    for flags in (_abi.RT_RENDER_NO_TAIL, _abi.RT_RENDER_TAIL_ONLY, _abi.RT_RENDER_ONE_STREAM):
+    for flags in (_abi.RT_RENDER_NO_TAIL, _abi.RT_RENDER_TAIL_ONLY, _abi.RT_RENDER_ONE_STREAM, _abi.RT_RENDER_ONE_KERNEL):   # (ONE_KERNEL is refused silently: the nodes are not in LDS)
         _, m = sc.render(cam, io, rt.RenderOptions(seed=2, flags=flags), want_mean=True)
         assert np.array_equal(m, base, equal_nan=True), flags
     mean_o = osc.render(co.to_c(), 64, 64, 16, 12, seed=2, threads=8)[1]
@@ -344,6 +344,8 @@ def test_result_does_not_depend_on_passes_kernel_split_or_ranks(earth):
         for ro in (rt.RenderOptions(seed=3, samples_per_pass=5), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_NO_TAIL),
                    rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_TAIL_ONLY), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_PROFILE),
                    rt.RenderOptions(seed=3, tile_w=8, tile_h=4), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_ONE_STREAM),
+                   rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_ONE_KERNEL), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_TWO_KERNELS),
+                   rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_ONE_KERNEL | _abi.RT_RENDER_NO_TAIL), rt.RenderOptions(seed=3, flags=_abi.RT_RENDER_TWO_KERNELS | _abi.RT_RENDER_NO_TAIL),
                    rt.RenderOptions(seed=3, samples_per_pass=5, flags=_abi.RT_RENDER_ONE_STREAM)):
             _, m = sc.render(cam, io, ro, want_mean=True)
             assert np.array_equal(m, base), (name, ro)
@@ -413,7 +415,9 @@ def test_full_size_properties_of_the_other_configurations(name, w, h):
     assert np.isfinite(mean).all() and mean.any()
     assert np.array_equal(rgb, np.minimum(np.floor(np.sqrt(np.clip(mean, 0, 1)) * 255.999), 255).astype(np.uint8))    # lib.rs:68-72
     # the frame does not depend on the schedule: unprofiled (cached calibration, two streams where they pay), one stream, short passes
-    for ro in (rt.RenderOptions(seed=1), rt.RenderOptions(seed=1, flags=_abi.RT_RENDER_ONE_STREAM), rt.RenderOptions(seed=1, samples_per_pass=3)):
+    # (these scenes have a handful of leaves: by default a bounce is one kernel that scans them; RT_RENDER_TWO_KERNELS is the traversal / shading pair)
+    for ro in (rt.RenderOptions(seed=1), rt.RenderOptions(seed=1, flags=_abi.RT_RENDER_ONE_STREAM), rt.RenderOptions(seed=1, samples_per_pass=3),
+               rt.RenderOptions(seed=1, flags=_abi.RT_RENDER_TWO_KERNELS)):
         _, m = sc.render(cam, io, ro, want_mean=True)
         assert np.array_equal(m, mean), ro
     thirds = [sc.render(cam, io, rt.RenderOptions(seed=1, rank=r, world_size=3), want_mean=True)[1] for r in range(3)]

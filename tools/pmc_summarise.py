@@ -70,9 +70,11 @@ def main(root, out_json, out_md):
         fe, wr = read_counters(os.path.join(root, cfg, "fetch")), read_counters(os.path.join(root, cfg, "write"))
         dur = read_durations(os.path.join(root, cfg, "stats"))
         rec = {"workload": work, "kernels": {}}
+        fused = "k_traverse" not in sq   # a handful of leaves: k_shade walks and shades, and no hit record is written or read
         for k in ("k_traverse", "k_shade"):
             if k not in sq:
                 continue
+            algo_k = 95 if (fused and k == "k_shade") else algo[k]
             s = sq[k]
             launches, ns = dur.get(k, [0, 0.0])
             hbm = (2.0 * fe[k].get("FETCH_SIZE", 0.0) + wr[k].get("WRITE_SIZE", 0.0)) * 1024.0
@@ -83,12 +85,13 @@ def main(root, out_json, out_md):
                  "salu_per_valu": round(s["SQ_INSTS_SALU"] / s["SQ_INSTS_VALU"], 3) if s.get("SQ_INSTS_VALU") else None,
                  "wait_share": round(s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"], 4) if s.get("SQ_WAVE_CYCLES") else None,
                  "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None,
-                 "hbm_bytes": hbm, "hbm_bytes_per_segment": round(hbm / seg, 2), "algorithmic_bytes_per_segment": algo[k],
+                 "hbm_bytes": hbm, "hbm_bytes_per_segment": round(hbm / seg, 2), "algorithmic_bytes_per_segment": algo_k, "walks_and_shades": bool(fused and k == "k_shade"),
                  "hbm_gbps": round(hbm / ns, 1) if ns else None,
                  "raw": {"sq": dict(s), "tcc": dict(tcc[k]), "FETCH_SIZE_KiB": fe[k].get("FETCH_SIZE"), "WRITE_SIZE_KiB": wr[k].get("WRITE_SIZE")}}
             rec["kernels"][k] = r
-            lines.append(f"| {cfg} ({work['width']}x{work['height']}, {work['spp']} spp, {seg / 1e6:.1f} M segments) | `{k}` | {launches} | {r['ms_total']} | "
-                         f"{r['valu_busy']} | {r['valu_lane_slots_per_segment']} | {r['l2_hit_rate']} | {r['hbm_bytes_per_segment']} ({algo[k]}) | {r['hbm_gbps']} | {r['wait_share']} |")
+            tag = " (walk + shade)" if fused and k == "k_shade" else ""
+            lines.append(f"| {cfg} ({work['width']}x{work['height']}, {work['spp']} spp, {seg / 1e6:.1f} M segments) | `{k}`{tag} | {launches} | {r['ms_total']} | "
+                         f"{r['valu_busy']} | {r['valu_lane_slots_per_segment']} | {r['l2_hit_rate']} | {r['hbm_bytes_per_segment']} ({algo_k}) | {r['hbm_gbps']} | {r['wait_share']} |")
         doc["configs"][cfg] = rec
     with open(out_json, "w") as fh:
         json.dump(doc, fh, indent=1)
