@@ -576,8 +576,24 @@ struct Ray {
 #define RT_NODE_PLAIN_BOX 0x40000000u
 #define RT_NODE_PLAIN_SPHERE 0x20000000u
 
-struct alignas(16) WalkNode { float x0, x1, y0, y1, z0, z1; uint32_t skip, prim; };
+// A node's box is held as centre and half-widths: the two plane parameters of an axis are then
+//   (c * inv - o * inv) -+ h * |inv|,   near first whatever the sign of the direction,
+// so the slab test needs no minimum / maximum per axis (see node_hit).  make_node_box rounds the half-widths up so that
+// [c - h, c + h] contains the box it is made from.
+struct alignas(16) WalkNode { float hx, hy, cx, cy, hz, cz; uint32_t skip, prim; };
 static_assert(sizeof(WalkNode) == 32, "node slot size");
+// (host side) Centre and half-width of the fp32 interval [lo, hi] such that c - h <= lo and c + h >= hi hold exactly
+// (evaluated in f64, where sums of two floats are exact).  An unbounded or NaN interval becomes (0, inf): every ray passes.
+inline void centre_half(float lo, float hi, float& c, float& h) {
+    if (!(lo - lo == 0.0f) || !(hi - hi == 0.0f)) { c = 0.0f; h = INFINITY; return; }
+    c = (float)(0.5 * ((double)lo + (double)hi));
+    h = (float)(0.5 * ((double)hi - (double)lo));
+    if (lo > hi) return;  // an empty interval stays empty (h < 0: the near plane lies behind the far one)
+    while ((double)c - (double)h > (double)lo || (double)c + (double)h < (double)hi) h = std::nextafterf(h, INFINITY);
+}
+inline void set_node_box(WalkNode& W, float x0, float x1, float y0, float y1, float z0, float z1) {
+    centre_half(x0, x1, W.cx, W.hx); centre_half(y0, y1, W.cy, W.hy); centre_half(z0, z1, W.cz, W.hz);
+}
 // Positions in the node array -- the links in the nodes, the walk's place, the noted leaves -- are byte offsets
 // (slot number * 32): a read from the array then needs no address arithmetic beyond its base.
 #define RT_NODE_STRIDE 32u
@@ -765,7 +781,8 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
     nodes.assign((size_t)at + 1, WalkNode{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, at * RT_NODE_STRIDE, at * RT_NODE_STRIDE});
     for (uint32_t i = 0; i < n_in; ++i) {
         const rt_bvh_node& N = tree[i];
-        WalkNode W{N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2], new_index[N.skip] * RT_NODE_STRIDE, (new_index[i] + 1u) * RT_NODE_STRIDE};
+        WalkNode W{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, new_index[N.skip] * RT_NODE_STRIDE, (new_index[i] + 1u) * RT_NODE_STRIDE};
+        set_node_box(W, N.min[0], N.max[0], N.min[1], N.max[1], N.min[2], N.max[2]);
         if (N.prim != RT_BVH_NONE) {
             W.prim = RT_NODE_LEAF | (N.prim & RT_BVH_EXACT) | (N.prim & RT_NODE_PRIM_MASK);
             const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
@@ -798,7 +815,7 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
                 std::memcpy(&nodes[new_index[i] + 2], rem, sizeof(rem));
                 auto down = [&](float x) { float f = (float)((double)x - pad); while ((double)f > (double)x - pad) f = std::nextafterf(f, -INFINITY); return f; };
                 auto up = [&](float x) { float f = (float)((double)x + pad); while ((double)f < (double)x + pad) f = std::nextafterf(f, INFINITY); return f; };
-                W.x0 = down(exact[0]); W.x1 = up(exact[3]); W.y0 = down(exact[1]); W.y1 = up(exact[4]); W.z0 = down(exact[2]); W.z1 = up(exact[5]);
+                set_node_box(W, down(exact[0]), up(exact[3]), down(exact[1]), up(exact[4]), down(exact[2]), up(exact[5]));
             } else if (exact_leaf(N)) {
                 const float exact[8] = {N.min[0], N.min[1], N.min[2], N.max[0], N.max[1], N.max[2], 0.0f, 0.0f};
                 std::memcpy(&nodes[new_index[i] + 1], exact, sizeof(exact));
@@ -811,7 +828,7 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
                 }
                 auto down = [&](float x) { float f = (float)((double)x - pad); while ((double)f > (double)x - pad) f = std::nextafterf(f, -INFINITY); return f; };
                 auto up = [&](float x) { float f = (float)((double)x + pad); while ((double)f < (double)x + pad) f = std::nextafterf(f, INFINITY); return f; };
-                W.x0 = down(N.min[0]); W.x1 = up(N.max[0]); W.y0 = down(N.min[1]); W.y1 = up(N.max[1]); W.z0 = down(N.min[2]); W.z1 = up(N.max[2]);
+                set_node_box(W, down(N.min[0]), up(N.max[0]), down(N.min[1]), up(N.max[1]), down(N.min[2]), up(N.max[2]));
             }
         }
         nodes[new_index[i]] = W;
@@ -829,20 +846,29 @@ struct Walk {
 };
 RT_HD void walk_init(Walk& w, float tmax) { w.i = 0; w.leaf_node = 0; w.tmax = tmax; w.t = 0.0f; w.prim = 0; w.side = 0; w.found = false; }
 
-// Slab test of a node with the ray given as (1 / direction, origin / direction): the two bounds of an axis are one
-// pair, so the six (bound * inv - oi) are three two-wide fused multiply-adds on the GPU.
+// Slab test of a node with the ray given as (1 / direction, origin / direction).  With the box as centre and half-widths
+// the parameters of the two planes of an axis are m -+ h * |inv|, m = c * inv - o * inv: the near one first for either
+// sign of the direction.  On the GPU that is two fused multiply-adds for the three m (one of them two-wide) and one two-wide
+// one per axis for (near, far); then a three-way maximum and minimum.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float F2 __attribute__((ext_vector_type(2)));
-RT_HD F2 fma2(float a0, float a1, float b, float c) { const F2 a = {a0, a1}, bb = {b, b}, cc = {c, c}; return __builtin_elementwise_fma(a, bb, cc); }
+RT_HD F2 fma2(float a0, float a1, float b0, float b1, float c0, float c1) { const F2 a = {a0, a1}, b = {b0, b1}, c = {c0, c1}; return __builtin_elementwise_fma(a, b, c); }
 #else
 struct F2 { float x, y; };
-RT_HD F2 fma2(float a0, float a1, float b, float c) { F2 r; r.x = fmaf(a0, b, c); r.y = fmaf(a1, b, c); return r; }
+RT_HD F2 fma2(float a0, float a1, float b0, float b1, float c0, float c1) { F2 r; r.x = fmaf(a0, b0, c0); r.y = fmaf(a1, b1, c1); return r; }
 #endif
-RT_HD bool node_hit(const WalkNode& N, V3 inv, V3 oi, float tmin, float tmax) {
-    const F2 x = fma2(N.x0, N.x1, inv.x, -oi.x), y = fma2(N.y0, N.y1, inv.y, -oi.y), z = fma2(N.z0, N.z1, inv.z, -oi.z);
-    const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), tmin));
-    const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), tmax));
+// (near, far) of the three axes and the comparison; `ainv` = |inv|
+RT_HD bool slab_hit(float cx, float cy, float cz, float hx, float hy, float hz, V3 inv, V3 ainv, V3 oi, float tmin, float tmax) {
+    const F2 mxy = fma2(cx, cy, inv.x, inv.y, -oi.x, -oi.y);
+    const float mz = fmaf(cz, inv.z, -oi.z);
+    const F2 x = fma2(-hx, hx, ainv.x, ainv.x, mxy.x, mxy.x), y = fma2(-hy, hy, ainv.y, ainv.y, mxy.y, mxy.y), z = fma2(-hz, hz, ainv.z, ainv.z, mz, mz);
+    const float tn = fmaxf(fmaxf(fmaxf(x.x, y.x), z.x), tmin);
+    const float tf = fminf(fminf(fminf(x.y, y.y), z.y), tmax);
     return tn <= tf;
+}
+RT_HD V3 abs3(V3 a) { return v3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+RT_HD bool node_hit(const WalkNode& N, V3 inv, V3 oi, float tmin, float tmax) {
+    return slab_hit(N.cx, N.cy, N.cz, N.hx, N.hy, N.hz, inv, abs3(inv), oi, tmin, tmax);
 }
 
 // One node step.  Returns the leaf's prim field when the ray now stands on a leaf whose primitive has to be
@@ -869,15 +895,13 @@ RT_HD uint32_t walk_step(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w)
 // LDS_AT_ZERO: the node array stands in LDS from address 0 on, so a node's position is its address (the caller has checked
 // that the kernel has no LDS of its own in front of the dynamic array).
 template <bool LDS_AT_ZERO>
-__device__ __forceinline__ void walk_step_flat(const SceneView& S, V3 inv, V3 oi, float tmin, Walk& w, uint32_t& p0, uint32_t& p1, unsigned long long& m0, unsigned long long& m1) {
+__device__ __forceinline__ void walk_step_flat(const SceneView& S, V3 inv, V3 ainv, V3 oi, float tmin, Walk& w, uint32_t& p0, uint32_t& p1, unsigned long long& m0, unsigned long long& m1) {
     typedef __attribute__((address_space(3))) const WalkNode* LdsNode;
     WalkNode N;
-    if (LDS_AT_ZERO) { const LdsNode at = reinterpret_cast<LdsNode>((size_t)w.i); N.x0 = at->x0; N.x1 = at->x1; N.y0 = at->y0; N.y1 = at->y1; N.z0 = at->z0; N.z1 = at->z1; N.skip = at->skip; N.prim = at->prim; }
+    if (LDS_AT_ZERO) { const LdsNode at = reinterpret_cast<LdsNode>((size_t)w.i); N.hx = at->hx; N.hy = at->hy; N.cx = at->cx; N.cy = at->cy; N.hz = at->hz; N.cz = at->cz; N.skip = at->skip; N.prim = at->prim; }
     else N = node_at(S.bvh, w.i);
-    const F2 x = fma2(N.x0, N.x1, inv.x, -oi.x), y = fma2(N.y0, N.y1, inv.y, -oi.y), z = fma2(N.z0, N.z1, inv.z, -oi.z);
-    const float tn = fmaxf(fmaxf(fminf(x.x, x.y), fminf(y.x, y.y)), fmaxf(fminf(z.x, z.y), tmin));
-    const float tf = fminf(fminf(fmaxf(x.x, x.y), fmaxf(y.x, y.y)), fminf(fmaxf(z.x, z.y), w.tmax));
-    const unsigned long long hit_m = __builtin_amdgcn_ballot_w64(tn <= tf) & ~m1;
+    const bool in_box = slab_hit(N.cx, N.cy, N.cz, N.hx, N.hy, N.hz, inv, ainv, oi, tmin, w.tmax);
+    const unsigned long long hit_m = __builtin_amdgcn_ballot_w64(in_box) & ~m1;
     const unsigned long long leaf_m = __builtin_amdgcn_ballot_w64(N.prim >= RT_NODE_LEAF) & hit_m;
     const uint32_t next = __builtin_amdgcn_inverse_ballot_w64(hit_m & ~leaf_m) ? N.prim : N.skip;  // (on the sentinel both are the sentinel)
     p1 = __builtin_amdgcn_inverse_ballot_w64(leaf_m & m0) ? w.i : p1;

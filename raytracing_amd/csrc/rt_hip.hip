@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 #endif
     bool active = false, exhausted = n_nodes == 0;
     Ray r; r.o = v3(0, 0, 0); r.d = v3(1, 1, 1); r.time = 0.0f;
-    V3 inv = v3(1, 1, 1), oi = v3(0, 0, 0);
+    V3 inv = v3(1, 1, 1), ainv = v3(1, 1, 1), oi = v3(0, 0, 0);
     // The walk's state between turns: the next node, the upper end of the ray interval (the accepted hit's t once there
     // is one) and the accepted primitive with the box side in the top bits, RT_HIT_NONE while nothing is accepted.
     uint32_t node = n_nodes;  // a lane without a ray rests on the sentinel slot
@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
                 const NtF2 b = __builtin_nontemporal_load(reinterpret_cast<const NtF2*>(&q.od1[at]));
                 r.o = v3(a.x, a.y, a.z); r.d = v3(a.w, b.x, b.y);
                 inv = walk_cap(ray_inv(r.d));  // capped for the node tests; the box leaves get the infinities back
+                ainv = abs3(inv);
                 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
                 node = has_negative_zero(r.d) ? n_nodes : 0u;  // (such a ray misses every bounding box: it is done at once)
                 t_end = RT_INF_F; best = RT_HIT_NONE;
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
             Walk w; w.i = node; w.tmax = fminf(t_end, RT_WALK_FAR);
             unsigned long long m0 = __ballot(p0 != RT_BVH_NONE), m1 = ~__ballot(p1 == RT_BVH_NONE);
 #pragma unroll
-            for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat<NODES_IN_LDS>(S, inv, oi, tmin, w, p0, p1, m0, m1);
+            for (int k = 0; k < RT_STEPS_PER_TURN; ++k) walk_step_flat<NODES_IN_LDS>(S, inv, ainv, oi, tmin, w, p0, p1, m0, m1);
             node = w.i;
         } else {
 #ifdef RT_TRAV_STATS
