@@ -206,7 +206,7 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #define RT_STUCK_MAX 12       // ... or once this many lanes cannot step (two leaves pending, or out of the tree with one)
 #endif
 #ifndef RT_STEPS_PER_TURN
-#define RT_STEPS_PER_TURN 10  // node steps between two looks at the wave's state
+#define RT_STEPS_PER_TURN 12  // node steps between two looks at the wave's state
 #endif
 #ifdef RT_TRAV_STATS
 // Analysis build only: what the waves of k_traverse spend their turns on (summed over all launches since the last read).
@@ -345,6 +345,9 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 // Register budgets: k_traverse is held to 80 VGPRs (4 waves per SIMD = 320 of the 512 registers of a lane) and k_shade
 // to 96, so that one shading workgroup (2 waves per SIMD) fits beside the traversal workgroup of the pass's other half.
 #define RT_SHADE_BS 512
+#ifndef RT_SHADE_PRIO
+#define RT_SHADE_PRIO 3
+#endif
 #define RT_SCAN_MAX_LEAVES 16u   // leaves up to which a bounce runs as one kernel that scans them
 // How k_shade gets a ray's closest hit:
 //   SHADE_HITS  from the hit records of a k_traverse launch;
@@ -391,6 +394,12 @@ __global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_sha
     extern __shared__ uint4 lds_nodes[];
     __shared__ uint32_t wave_cnt[2][RT_SHADE_BS / 64];
     __shared__ uint32_t block_base[2];
+    // Shading waves run beside the traversal workgroup of the pass's other half (two streams) and spend most of their time
+    // waiting on queue memory: at a higher issue priority their few instructions go ahead of the traversal's whenever they
+    // are ready, the shading kernel is gone long before the traversal next to it ends, and the frame is left with the sum
+    // of the two kernels' instruction issue (final_scene: 507 -> 573 Msamples/s; raising the traversal's priority instead
+    // changed nothing).
+    __builtin_amdgcn_s_setprio(RT_SHADE_PRIO);
     const SceneView S = stage_nodes<MODE != SHADE_HITS>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
