@@ -124,6 +124,19 @@ struct Perlin {
     explicit Perlin(uint32_t seed);
     explicit Perlin(const std::array<uint8_t, 256>& t) : table(t) {}
 };
+// Stand-ins for the crate's `Fbm` and `Turbulence<Perlin>` with the crate's defaults (Fbm: 6 octaves, lacunarity 2 pi / 3,
+// persistence 0.5, octave i seeded with seed + i; Turbulence: power 1, roughness 3, distortion functions seeded with seed,
+// seed + 1, seed + 2; frequencies are 1).  No example of the reference uses them: `Texture::Noise` takes any `NoiseFn`
+// (textures.rs:14-17), these are the two more the device can evaluate.
+struct Fbm {
+    uint32_t seed = 0, octaves = 6;
+    double lacunarity = 2.0943951023931953, persistence = 0.5;
+};
+struct Turbulence {
+    Perlin source;
+    uint32_t seed = 0, roughness = 3;
+    double power = 1.0, lacunarity = 2.0943951023931953, persistence = 0.5;  // (lacunarity, persistence: of the distortion functions)
+};
 }  // namespace noise
 
 namespace textures {
@@ -135,6 +148,8 @@ public:
     static Texture SolidColor(const Vec3& color);
     static Texture Checkered(const Texture& odd, const Texture& even);
     static Texture Noise(double scale, const noise::Perlin& noise);
+    static Texture Noise(double scale, const noise::Fbm& noise);
+    static Texture Noise(double scale, const noise::Turbulence& noise);
     static Texture Image(uint32_t width, uint32_t height, std::vector<uint8_t> rgb);
     static Texture image(const std::string& path);  // textures.rs:41; reads binary PPM (P6), 8 bit
     const Node& node() const { return *n_; }

@@ -117,12 +117,25 @@ typedef struct rt_material {
 
 /* Texture (src/textures.rs:8-19). */
 enum { RT_TEX_SOLID = 0, RT_TEX_CHECKERED = 1, RT_TEX_NOISE = 2, RT_TEX_IMAGE = 3 };
+/* Noise { scale, noise } (textures.rs:14-17) holds an open `dyn NoiseFn`; the examples only ever put noise::Perlin there
+ * (perlin.rs:40, final_scene.rs:160).  The device evaluates three functions of the noise crate's family, chosen by the low
+ * byte of rt_texture.odd of a noise texture (0, the value every description written before these existed carries, is
+ * Perlin).  Fbm and Turbulence are extensions beyond what the reference's examples use: no reference image depends on them.
+ *   RT_NOISE_PERLIN      gradient noise over permutation table `resource`;
+ *   RT_NOISE_FBM         sum over octaves i < n of  persistence^i * Perlin_i(point * lacunarity^i),  Perlin_i over table
+ *                        resource + i (the crate's Fbm seeds its octave i with seed + i);
+ *   RT_NOISE_TURBULENCE  Perlin over table `even` at the point displaced, per coordinate c in (x, y, z), by
+ *                        power * Fbm_c(point + offset_c): Fbm_c has `n` octaves over tables resource + c + i (the crate's
+ *                        Turbulence seeds its three distortion functions with seed, seed + 1, seed + 2), offset_c are the
+ *                        crate's fixed fractions k / 65536.
+ * n = bits 8..15 of `odd` (1..32); lacunarity, persistence, power = color[0], color[1], color[2]. */
+enum { RT_NOISE_PERLIN = 0, RT_NOISE_FBM = 1, RT_NOISE_TURBULENCE = 2 };
 typedef struct rt_texture {
     uint32_t kind;
-    float color[3];    /* SolidColor */
-    uint32_t odd, even;/* Checkered: indices of the two child textures */
+    float color[3];    /* SolidColor; Noise: lacunarity, persistence, power (Fbm / Turbulence) */
+    uint32_t odd, even;/* Checkered: indices of the two child textures; Noise: function | octaves << 8, source table (Turbulence) */
     float scale;       /* Noise */
-    uint32_t resource; /* Noise: permutation table index; Image: image index */
+    uint32_t resource; /* Noise: (first) permutation table index; Image: image index */
 } rt_texture;          /* 32 bytes */
 
 /* Image(RgbImage) (textures.rs:18): 8-bit RGB, row 0 at the top, 3 bytes per texel. */

@@ -493,6 +493,28 @@ static double perlin3(const PermTable& pt, double x, double y, double z) {
     return r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
 }
 
+// noise 0.6.0 `Fbm` and `Turbulence<Perlin>` (third party, restated from memory; parity unpinned; no example of the
+// reference uses them -- Texture::Noise takes any NoiseFn, textures.rs:14-17).  Fbm: sum over octaves i of
+// persistence^i * Perlin(seed + i)(point * lacunarity^i), frequency 1.  Turbulence: the source at the point displaced per
+// coordinate by power * Fbm(seed + c)(point + fixed offset), the distortion functions with `roughness` octaves.
+static double fbm3(const PermTable* tables, uint32_t octaves, double lacunarity, double persistence, double x, double y, double z) {
+    double result = 0.0, amplitude = 1.0;
+    for (uint32_t i = 0; i < octaves; ++i) {
+        result += perlin3(tables[i], x, y, z) * amplitude;
+        amplitude *= persistence;
+        x *= lacunarity; y *= lacunarity; z *= lacunarity;
+    }
+    return result;
+}
+static double turbulence3(const PermTable* tables, const PermTable& source, uint32_t roughness, double lacunarity, double persistence, double power,
+                          double x, double y, double z) {
+    const double u = 1.0 / 65536.0;
+    const double dx = fbm3(tables, roughness, lacunarity, persistence, x + 12414.0 * u, y + 65124.0 * u, z + 31337.0 * u);
+    const double dy = fbm3(tables + 1, roughness, lacunarity, persistence, x + 26519.0 * u, y + 18128.0 * u, z + 60493.0 * u);
+    const double dz = fbm3(tables + 2, roughness, lacunarity, persistence, x + 53820.0 * u, y + 11213.0 * u, z + 44845.0 * u);
+    return perlin3(source, x + dx * power, y + dy * power, z + dz * power);
+}
+
 // ---------------------------------------------------------------- Texture
 // textures.rs:8-19, :46-78
 struct Texture;
@@ -502,6 +524,8 @@ struct Texture {
     Vec3 color{};
     TexP odd, even;
     double scale = 1.0; PermTable perm{};
+    int function = 0;  // 0 Perlin, 1 Fbm, 2 Turbulence (perm: its source)
+    uint32_t octaves = 0; double lacunarity = 0.0, persistence = 0.0, power = 0.0; std::vector<PermTable> octave_tables;
     uint32_t width = 0, height = 0; std::vector<uint8_t> rgb;
     Vec3 color_at(double u, double v, const Vec3& p) const {
         switch (kind) {
@@ -512,6 +536,9 @@ struct Texture {
                 return even->color_at(u, v, p);
             case Noise:
                 CNT(tex_noise);
+                if (function == 1) return V(1.0, 1.0, 1.0) * fbm3(octave_tables.data(), octaves, lacunarity, persistence, p[0] * scale, p[1] * scale, p[2] * scale);
+                if (function == 2)
+                    return V(1.0, 1.0, 1.0) * turbulence3(octave_tables.data(), perm, octaves, lacunarity, persistence, power, p[0] * scale, p[1] * scale, p[2] * scale);
                 return V(1.0, 1.0, 1.0) * perlin3(perm, p[0] * scale, p[1] * scale, p[2] * scale);
             case Image: {
                 CNT(tex_image);
@@ -950,6 +977,24 @@ void orc_shape_free(void* s) { delete (ShapeP*)s; }
 void* orc_tex_solid(const double* c) { return new TexP(tex_solid(v3(c))); }
 void* orc_tex_checkered(void* odd, void* even) { return new TexP(tex_checker(*(TexP*)odd, *(TexP*)even)); }
 void* orc_tex_noise(double scale, const uint8_t* perm256) { PermTable pt; std::memcpy(pt.values, perm256, 256); return new TexP(tex_noise(scale, pt)); }
+static std::vector<PermTable> tables_from_seeds(uint32_t seed, uint32_t count) {
+    std::vector<PermTable> out;
+    for (uint32_t i = 0; i < count; ++i) out.push_back(perm_table_from_seed(seed + i));
+    return out;
+}
+void* orc_tex_noise_fbm(double scale, uint32_t seed, uint32_t octaves, double lacunarity, double persistence) {
+    if (octaves < 1 || octaves > 32) return nullptr;
+    auto t = std::make_shared<Texture>(); t->kind = Texture::Noise; t->scale = scale; t->function = 1; t->octaves = octaves;
+    t->lacunarity = lacunarity; t->persistence = persistence; t->octave_tables = tables_from_seeds(seed, octaves);
+    return new TexP(t);
+}
+void* orc_tex_noise_turbulence(double scale, const uint8_t* source_perm256, uint32_t seed, uint32_t roughness, double power, double lacunarity, double persistence) {
+    if (roughness < 1 || roughness > 32) return nullptr;
+    auto t = std::make_shared<Texture>(); t->kind = Texture::Noise; t->scale = scale; t->function = 2; t->octaves = roughness;
+    std::memcpy(t->perm.values, source_perm256, 256);
+    t->lacunarity = lacunarity; t->persistence = persistence; t->power = power; t->octave_tables = tables_from_seeds(seed, roughness + 2);
+    return new TexP(t);
+}
 void* orc_tex_image(uint32_t w, uint32_t h, const uint8_t* rgb) { return new TexP(tex_image(w, h, rgb)); }
 void orc_tex_free(void* t) { delete (TexP*)t; }
 

@@ -16,6 +16,7 @@ RT_RENDER_PROFILE, RT_RENDER_NO_TAIL, RT_RENDER_TAIL_ONLY, RT_RENDER_NODES_IN_GL
 RT_GEOM_SPHERE, RT_GEOM_MOVING_SPHERE, RT_GEOM_RECT, RT_GEOM_BOX = 0, 1, 2, 3
 RT_PRIM_FLIP, RT_PRIM_MEDIUM, RT_PRIM_INERT = 1, 2, 4
 RT_BVH_NONE, RT_BVH_EXACT = 0xFFFFFFFF, 0x80000000
+RT_NOISE_PERLIN, RT_NOISE_FBM, RT_NOISE_TURBULENCE = 0, 1, 2
 RT_K_NAMES = ("raygen", "traverse", "shade", "tail", "resolve", "finalize")
 
 
@@ -144,6 +145,8 @@ def builder_symbols(prefix):
         prefix + "tex_solid": (_P, [_D3]),
         prefix + "tex_checkered": (_P, [_P, _P]),
         prefix + "tex_noise": (_P, [C.c_double, C.c_void_p]),
+        prefix + "tex_noise_fbm": (_P, [C.c_double, C.c_uint32, C.c_uint32, C.c_double, C.c_double]),
+        prefix + "tex_noise_turbulence": (_P, [C.c_double, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_double]),
         prefix + "tex_image": (_P, [C.c_uint32, C.c_uint32, C.c_void_p]),
         prefix + "tex_free": (None, [_P]),
         prefix + "mat_lambertian": (_P, [_P]),

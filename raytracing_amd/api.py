@@ -125,6 +125,21 @@ class Texture:
         """noise::Perlin with an explicit 256-entry permutation table (default: the seed-0 table)."""
         return Texture("noise", scale=float(scale), table=None if perm_table is None else bytes(perm_table))
 
+    LACUNARITY = 2.0943951023931953  # 2 pi / 3, the noise crate's default
+
+    @staticmethod
+    def Fbm(scale, seed=0, octaves=6, lacunarity=LACUNARITY, persistence=0.5):
+        """Noise { scale, noise: Fbm } with the noise crate's defaults; octave i is a Perlin of seed + i.  Not used by any example of
+        the reference (an extension: textures.rs:14-17 takes any NoiseFn)."""
+        return Texture("fbm", scale=float(scale), seed=int(seed), octaves=int(octaves), lacunarity=float(lacunarity), persistence=float(persistence))
+
+    @staticmethod
+    def Turbulence(scale, seed=0, roughness=3, power=1.0, source_table=None, lacunarity=LACUNARITY, persistence=0.5):
+        """Noise { scale, noise: Turbulence<Perlin> }: the source Perlin (default: seed 0) at the point displaced by three Fbm
+        functions of seeds seed, seed + 1, seed + 2 with `roughness` octaves.  An extension like Fbm."""
+        return Texture("turbulence", scale=float(scale), seed=int(seed), roughness=int(roughness), power=float(power),
+                       table=None if source_table is None else bytes(source_table), lacunarity=float(lacunarity), persistence=float(persistence))
+
     @staticmethod
     def Image(rgb: np.ndarray):
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
@@ -150,6 +165,22 @@ class Texture:
             else:
                 buf = (C.c_uint8 * 256).from_buffer_copy(table)
             return be.tex_noise(kw["scale"], buf)
+        if k == "fbm":
+            t = be.tex_noise_fbm(kw["scale"], kw["seed"], kw["octaves"], kw["lacunarity"], kw["persistence"])
+            if not t:
+                raise ValueError("Texture.Fbm: 1 to 32 octaves")
+            return t
+        if k == "turbulence":
+            table = kw["table"]
+            if table is None:
+                buf = (C.c_uint8 * 256)()
+                be.perm_table(0, buf)
+            else:
+                buf = (C.c_uint8 * 256).from_buffer_copy(table)
+            t = be.tex_noise_turbulence(kw["scale"], buf, kw["seed"], kw["roughness"], kw["power"], kw["lacunarity"], kw["persistence"])
+            if not t:
+                raise ValueError("Texture.Turbulence: roughness 1 to 32")
+            return t
         if k == "image":
             rgb = kw["rgb"]
             return be.tex_image(rgb.shape[1], rgb.shape[0], rgb.ctypes.data_as(C.c_void_p))

@@ -52,6 +52,15 @@ void* rth_tex_noise(double scale, const uint8_t* perm256) {
     std::array<uint8_t, 256> t; std::memcpy(t.data(), perm256, 256);
     return new Texture(Texture::Noise(scale, noise::Perlin(t)));
 }
+void* rth_tex_noise_fbm(double scale, uint32_t seed, uint32_t octaves, double lacunarity, double persistence) {
+    noise::Fbm f; f.seed = seed; f.octaves = octaves; f.lacunarity = lacunarity; f.persistence = persistence;
+    try { return new Texture(Texture::Noise(scale, f)); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void* rth_tex_noise_turbulence(double scale, const uint8_t* source_perm256, uint32_t seed, uint32_t roughness, double power, double lacunarity, double persistence) {
+    std::array<uint8_t, 256> t; std::memcpy(t.data(), source_perm256, 256);
+    noise::Turbulence n{noise::Perlin(t), seed, roughness, power, lacunarity, persistence};
+    try { return new Texture(Texture::Noise(scale, n)); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
 void* rth_tex_image(uint32_t w, uint32_t h, const uint8_t* rgb) {
     try { return new Texture(Texture::Image(w, h, std::vector<uint8_t>(rgb, rgb + (size_t)3 * w * h))); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }

@@ -173,7 +173,7 @@ namespace noise {
 // Permutation table of noise 0.6.0's PermutationTable::new(seed): 0..=255 shuffled (rand 0.7
 // SliceRandom::shuffle) by an XorShiftRng seeded with the bytes [1,0,0,0, seed, seed, seed].
 // Restated from the crates' published sources from memory; not verifiable offline.
-static std::array<uint8_t, 256> table_from_seed(uint32_t seed) {
+std::array<uint8_t, 256> table_from_seed(uint32_t seed) {
     uint32_t s[4] = {1u, seed, seed, seed};
     auto next = [&s]() {
         uint32_t x = s[0], t = x ^ (x << 11);
@@ -204,7 +204,9 @@ struct Texture::Node {
     Kind kind;
     Vec3 color;
     std::shared_ptr<const Node> odd, even;
-    double scale = 1.0; std::array<uint8_t, 256> table{};
+    double scale = 1.0; std::array<uint8_t, 256> table{};  // table: Perlin's, or a Turbulence's source
+    uint32_t function = RT_NOISE_PERLIN, octaves = 0; double lacunarity = 0.0, persistence = 0.0, power = 0.0;
+    std::vector<uint8_t> octave_tables;                    // Fbm / Turbulence: the consecutive tables of seed, seed + 1, ...
     uint32_t width = 0, height = 0; std::vector<uint8_t> rgb;
 };
 Texture Texture::SolidColor(const Vec3& color) { auto n = std::make_shared<Node>(); n->kind = Kind::SolidColor; n->color = color; return Texture(n); }
@@ -213,6 +215,24 @@ Texture Texture::Checkered(const Texture& odd, const Texture& even) {
 }
 Texture Texture::Noise(double scale, const noise::Perlin& p) {
     auto n = std::make_shared<Node>(); n->kind = Kind::Noise; n->scale = scale; n->table = p.table; return Texture(n);
+}
+static std::vector<uint8_t> tables_from_seeds(uint32_t seed, uint32_t count) {
+    std::vector<uint8_t> out;
+    for (uint32_t i = 0; i < count; ++i) { const auto t = noise::table_from_seed(seed + i); out.insert(out.end(), t.begin(), t.end()); }
+    return out;
+}
+Texture Texture::Noise(double scale, const noise::Fbm& f) {
+    if (f.octaves < 1 || f.octaves > 32) throw std::invalid_argument("Texture::Noise: an Fbm has 1 to 32 octaves");
+    auto n = std::make_shared<Node>(); n->kind = Kind::Noise; n->scale = scale; n->function = RT_NOISE_FBM; n->octaves = f.octaves;
+    n->lacunarity = f.lacunarity; n->persistence = f.persistence; n->octave_tables = tables_from_seeds(f.seed, f.octaves);
+    return Texture(n);
+}
+Texture Texture::Noise(double scale, const noise::Turbulence& t) {
+    if (t.roughness < 1 || t.roughness > 32) throw std::invalid_argument("Texture::Noise: a Turbulence has roughness 1 to 32");
+    auto n = std::make_shared<Node>(); n->kind = Kind::Noise; n->scale = scale; n->function = RT_NOISE_TURBULENCE; n->octaves = t.roughness;
+    n->lacunarity = t.lacunarity; n->persistence = t.persistence; n->power = t.power; n->table = t.source.table;
+    n->octave_tables = tables_from_seeds(t.seed, t.roughness + 2);  // three distortion functions, seeds seed, seed + 1, seed + 2
+    return Texture(n);
 }
 Texture Texture::Image(uint32_t width, uint32_t height, std::vector<uint8_t> rgb) {
     if (width == 0 || height == 0 || rgb.size() != (size_t)3 * width * height) throw std::invalid_argument("Texture::Image: size mismatch");
@@ -313,11 +333,21 @@ uint32_t Scene::Impl::add_texture(const textures::Texture::Node& t) {
             break;
         case K::Noise: {
             r.kind = RT_TEX_NOISE; r.scale = (float)t.scale;
-            uint32_t found = UINT32_MAX;
-            for (uint32_t k = 0; k < perm_tables.size() / 256; ++k)
-                if (std::memcmp(&perm_tables[256 * k], t.table.data(), 256) == 0) { found = k; break; }
-            if (found == UINT32_MAX) { found = (uint32_t)(perm_tables.size() / 256); perm_tables.insert(perm_tables.end(), t.table.begin(), t.table.end()); }
-            r.resource = found;
+            // a run of whole tables in perm_tables equal to `bytes`, appended if there is none
+            auto place = [this](const uint8_t* bytes, size_t n_bytes) {
+                for (size_t at = 0; at + n_bytes <= perm_tables.size(); at += 256)
+                    if (std::memcmp(&perm_tables[at], bytes, n_bytes) == 0) return (uint32_t)(at / 256);
+                const uint32_t first = (uint32_t)(perm_tables.size() / 256);
+                perm_tables.insert(perm_tables.end(), bytes, bytes + n_bytes);
+                return first;
+            };
+            if (t.function == RT_NOISE_PERLIN) r.resource = place(t.table.data(), 256);
+            else {
+                r.odd = t.function | (t.octaves << 8);
+                r.color[0] = (float)t.lacunarity; r.color[1] = (float)t.persistence; r.color[2] = (float)t.power;
+                r.resource = place(t.octave_tables.data(), t.octave_tables.size());
+                if (t.function == RT_NOISE_TURBULENCE) r.even = place(t.table.data(), 256);
+            }
             break;
         }
         case K::Image: {

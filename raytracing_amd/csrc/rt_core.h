@@ -1025,6 +1025,28 @@ RT_HD float perlin3(const uint8_t* perm, V3 p) {
     return fminf(fmaxf(r, -1.0f), 1.0f);
 }
 
+// The other two noise functions a noise texture can name (rt_abi.h: RT_NOISE_*), after the noise crate's `Fbm` and
+// `Turbulence` (third party, restated like Perlin; no reference example uses them).  Octave i of an Fbm draws on the
+// permutation table i places behind the function's first.
+RT_HD float fbm3(const uint8_t* perm, uint32_t octaves, float lacunarity, float persistence, V3 p) {
+    float result = 0.0f, amplitude = 1.0f;
+    for (uint32_t i = 0; i < octaves; ++i) {
+        result = fmaf(perlin3(perm + 256u * i, p), amplitude, result);
+        amplitude *= persistence;
+        p = p * lacunarity;
+    }
+    return result;
+}
+// The source Perlin at the point displaced by three Fbm functions (tables `perm`, `perm + 256`, `perm + 512` onwards),
+// each looked up at the point shifted by the crate's fixed offsets.
+RT_HD float turbulence3(const uint8_t* perm, const uint8_t* source, uint32_t roughness, float lacunarity, float persistence, float power, V3 p) {
+    const float u = 1.0f / 65536.0f;
+    const float dx = fbm3(perm, roughness, lacunarity, persistence, v3(p.x + 12414.0f * u, p.y + 65124.0f * u, p.z + 31337.0f * u));
+    const float dy = fbm3(perm + 256u, roughness, lacunarity, persistence, v3(p.x + 26519.0f * u, p.y + 18128.0f * u, p.z + 60493.0f * u));
+    const float dz = fbm3(perm + 512u, roughness, lacunarity, persistence, v3(p.x + 53820.0f * u, p.y + 11213.0f * u, p.z + 44845.0f * u));
+    return perlin3(source, v3(fmaf(dx, power, p.x), fmaf(dy, power, p.y), fmaf(dz, power, p.z)));
+}
+
 // Texture::color_at (textures.rs:46-78).
 RT_HD V3 texture_color(const SceneView& S, uint32_t tex, float u, float v, V3 p) {
     rt_texture T = S.textures[tex];
@@ -1033,7 +1055,13 @@ RT_HD V3 texture_color(const SceneView& S, uint32_t tex, float u, float v, V3 p)
         T = S.textures[odd ? T.odd : T.even];
     }
     if (T.kind == RT_TEX_NOISE) {
-        float n = perlin3(S.perm + 256u * T.resource, v3(p.x * T.scale, p.y * T.scale, p.z * T.scale));
+        const V3 q = v3(p.x * T.scale, p.y * T.scale, p.z * T.scale);
+        const uint8_t* table = S.perm + 256u * T.resource;
+        const uint32_t fn = T.odd & 255u, octaves = (T.odd >> 8) & 255u;
+        float n;
+        if (fn == RT_NOISE_PERLIN) n = perlin3(table, q);
+        else if (fn == RT_NOISE_FBM) n = fbm3(table, octaves, T.color[0], T.color[1], q);
+        else n = turbulence3(table, S.perm + 256u * T.even, octaves, T.color[0], T.color[1], T.color[2], q);
         return v3(n, n, n);  // may be negative: the reference does not clamp
     }
     if (T.kind == RT_TEX_IMAGE) {

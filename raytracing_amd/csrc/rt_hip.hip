@@ -60,6 +60,7 @@ struct PassParams {
     uint32_t max_depth;
     uint32_t up_axis; float up_sign;  // the axis the camera's up vector (cam.v) is closest to, and its sign there
     uint32_t n_counts;     // queue lengths come in two arrays of this many entries, one behind the other (see queue_slot)
+    uint32_t overlapped;   // the pass runs as two halves on two streams: kernels of one half run beside kernels of the other
     const uint32_t* owned; // global pixel id (j * width + i) of every owned pixel
 };
 
@@ -394,12 +395,12 @@ __global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_sha
     extern __shared__ uint4 lds_nodes[];
     __shared__ uint32_t wave_cnt[2][RT_SHADE_BS / 64];
     __shared__ uint32_t block_base[2];
-    // Shading waves run beside the traversal workgroup of the pass's other half (two streams) and spend most of their time
+    // Shading waves that run beside the traversal workgroup of the pass's other half (two streams) spend most of their time
     // waiting on queue memory: at a higher issue priority their few instructions go ahead of the traversal's whenever they
     // are ready, the shading kernel is gone long before the traversal next to it ends, and the frame is left with the sum
     // of the two kernels' instruction issue (final_scene: 507 -> 573 Msamples/s; raising the traversal's priority instead
-    // changed nothing).
-    __builtin_amdgcn_s_setprio(RT_SHADE_PRIO);
+    // changed nothing).  On its own the kernel is a few per cent slower with the priority raised, so it is only raised there.
+    if (MODE == SHADE_HITS && P.overlapped) __builtin_amdgcn_s_setprio(RT_SHADE_PRIO);
     const SceneView S = stage_nodes<MODE != SHADE_HITS>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -686,7 +687,14 @@ static rt_status validate_desc(const rt_scene_desc* D) {
         const rt_texture& T = D->textures[i];
         if (T.kind > RT_TEX_IMAGE) return fail(RT_ERR_INVALID_ARGUMENT, "texture kind out of range");
         if (T.kind == RT_TEX_CHECKERED && (T.odd >= D->n_textures || T.even >= D->n_textures)) return fail(RT_ERR_INVALID_ARGUMENT, "checker child out of range");
-        if (T.kind == RT_TEX_NOISE && T.resource >= D->n_perm_tables) return fail(RT_ERR_INVALID_ARGUMENT, "noise permutation table out of range");
+        if (T.kind == RT_TEX_NOISE) {
+            const uint32_t fn = T.odd & 255u, octaves = (T.odd >> 8) & 255u;
+            if (fn > RT_NOISE_TURBULENCE) return fail(RT_ERR_UNSUPPORTED, "noise texture names a function the kernels do not implement");
+            if (fn != RT_NOISE_PERLIN && (octaves < 1 || octaves > 32)) return fail(RT_ERR_INVALID_ARGUMENT, "a noise texture's octave count must be 1..32");
+            const uint64_t tables = fn == RT_NOISE_PERLIN ? 1u : (fn == RT_NOISE_FBM ? octaves : octaves + 2u);  // consecutive tables from `resource` on
+            if ((uint64_t)T.resource + tables > D->n_perm_tables || (fn == RT_NOISE_TURBULENCE && T.even >= D->n_perm_tables))
+                return fail(RT_ERR_INVALID_ARGUMENT, "noise permutation table out of range");
+        }
         if (T.kind == RT_TEX_IMAGE) {
             if (T.resource >= D->n_images) return fail(RT_ERR_INVALID_ARGUMENT, "image index out of range");
             const rt_image& I = D->images[T.resource];
@@ -1063,7 +1071,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     P.cam = *cam; P.width = W; P.height = H; P.n_owned = n_owned;
     P.owned_magic = n_owned > 1 ? ~0ull / n_owned + 1 : 0;
     P.k0 = (uint32_t)ro->seed; P.k1 = (uint32_t)(ro->seed >> 32); P.max_depth = depth; P.owned = ws.owned;
-    P.n_counts = n_counts;
+    P.n_counts = n_counts; P.overlapped = 0;
     P.up_axis = 1;
     for (uint32_t c = 0; c < 3; ++c) if (std::fabs(cam->v[c]) > std::fabs(cam->v[P.up_axis])) P.up_axis = c;
     P.up_sign = cam->v[P.up_axis] < 0.0 ? -1.0f : 1.0f;
@@ -1121,7 +1129,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             const uint32_t ns_k = ns / n_halves + ((uint32_t)k < ns % n_halves ? 1u : 0u);
             const size_t path_off = (size_t)sample_off * n_owned;
             h.stream = k == 0 ? stream : sc->side_stream[k - 1];
-            h.P = P; h.P.sample_base = (uint32_t)s0 + sample_off; h.P.n_paths = ns_k * n_owned;
+            h.P = P; h.P.sample_base = (uint32_t)s0 + sample_off; h.P.n_paths = ns_k * n_owned; h.P.overlapped = n_halves > 1 ? 1u : 0u;
             for (int j = 0; j < 2; ++j) { h.q[j].od0 = ws.q[j].od0 + path_off; h.q[j].od1 = ws.q[j].od1 + path_off; h.q[j].thr = ws.q[j].thr + path_off; }
             h.hits = ws.hits + path_off; h.counts = ws.counts + (size_t)k * 2 * n_counts; h.values = ws.values + path_off; h.cur = 0;
             sample_off += ns_k;

@@ -473,3 +473,47 @@ def test_pixels_split_over_device_contexts(earth):
     assert rt.pixels(cam, sc, io, seed=5, devices=[0, 0, 0]) == rt.pixels(cam, sc, io, seed=5)
     with pytest.raises(RuntimeError):
         rt.pixels(cam, sc, io, seed=5, devices=[0, 999])
+
+
+def test_noise_kinds_beyond_perlin():
+    """Noise textures that name an Fbm or a Turbulence (rt_abi.h RT_NOISE_*; an extension, no reference example uses them):
+    shading records along the paths of a scene that wears them, and its image with shared random streams, against the oracle."""
+    from scenes_util import noise_kinds_scene
+    objects, background, co_kw = noise_kinds_scene()
+    sc, osc = rt.Scene(objects, background), OracleScene(objects, background)
+    co = rt.CameraOptions(**co_kw)
+    oco = co.to_c()
+    lib = oracle()
+    rng = np.random.default_rng(12)
+    compared, seen = 0, set()
+    for b, (o, d, t) in enumerate(path_rays(osc, oco, 48, 32, 6, 1500, 4, rng)):
+        ho = osc.intersect(o, d, t, seed=6)
+        hg = sc.intersect_batch(o, d, t, seed=6)
+        compare_hits(hg, ho, "noise kinds scene", allow_flag_mismatch=1e-3, origins=o)
+        idx = np.where((ho["hit"] == 1) & (hg["hit"] == 1) & (ho["prim"] == hg["prim"]))[0][:500]
+        keys = np.stack([idx, np.full(len(idx), 2), np.full(len(idx), b)], axis=1).astype(np.uint32)
+        got = sc.scatter_batch(hg[idx], seed=6, keys=keys)
+        for j, k in enumerate(idx):
+            hk = ho[k:k + 1].copy()
+            s2, c2, o2, d2 = C.c_int32(), (C.c_double * 3)(), (C.c_double * 3)(), (C.c_double * 3)()
+            lib.orc_scene_scatter(osc.h, hk.ctypes.data, 6, int(k), 2, b, C.byref(s2), c2, o2, d2)
+            assert got[j]["scattered"] == s2.value
+            # (the texture is looked up at the fp32 hit point: the colour carries the point's rounding times the noise's slope)
+            assert np.allclose(got[j]["color"], np.array(c2), rtol=1e-4, atol=1e-4, equal_nan=True), int(hg[k]["prim"])
+            seen.add(int(hg[k]["prim"]))
+            compared += 1
+    assert seen == {0, 1, 2, 3} and compared > 800
+    cam = rt.Camera(co)
+    w, h, spp = 96, 64, 32
+    rgb, mean = sc.render(cam, rt.ImageOptions(h, w, spp, 50), rt.RenderOptions(seed=1), want_mean=True)
+    a, amean, _, _ = osc.render(oco, w, h, spp, 50, seed=1, threads=16)
+    bb, _, _, _ = osc.render(oco, w, h, spp, 50, seed=2, threads=16)
+    floor, err = rmse(a, bb), rmse(rgb, a)
+    assert not np.isnan(mean).any()
+    assert err <= 0.5 * floor, (err, floor)
+    assert abs(mean.mean() - amean.mean()) <= 0.02 * abs(amean.mean()) + 1e-3
+    # a description that asks for more tables than it brings is refused
+    bad = rt.Scene([rt.Object(rt.Shape.Sphere((0, 0, 0), 1.0), rt.Material.Lambertian(rt.Texture.Fbm(1.0, octaves=4)))], (0, 0, 0))
+    bad.desc.n_perm_tables = 3
+    with pytest.raises(_abi.RtError):
+        bad.device()

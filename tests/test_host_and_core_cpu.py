@@ -485,3 +485,82 @@ def test_wrapped_sphere_leaves_carry_the_centre_in_the_outer_frame():
     got = twin_intersect(sc, o, dd, t)
     nsame, _ = compare_hits(got, ref, "wrapped sphere", allow_flag_mismatch=2e-3, origins=o)
     assert nsame > 500
+
+
+def test_noise_kinds_fbm_and_turbulence():
+    """The two noise functions beyond Perlin that a Noise texture can name (rt_abi.h RT_NOISE_*): their definitions by hand on the
+    oracle, the flattened description, and the kernel code (CPU build) against the oracle at random points."""
+    from oracle_lib import oracle_backend
+    from scenes_util import noise_kinds_scene
+    lib, tw, be = oracle(), twin(), oracle_backend()
+    T = rt.Texture
+    tables = []
+    for seed in range(8):
+        buf = (C.c_uint8 * 256)()
+        lib.orc_perm_table(seed, buf)
+        tables.append(buf)
+
+    def colour(tex, p):
+        h = tex.build(be)
+        out = (C.c_double * 3)()
+        lib.orc_texture_color(h, 0.0, 0.0, (C.c_double * 3)(*p), out)
+        be.tex_free(h)
+        assert out[0] == out[1] == out[2]
+        return out[0]
+
+    def perlin(seed, p):
+        return lib.orc_perlin3(tables[seed], *p)
+
+    p = np.array([0.37, -1.21, 2.6])
+    assert colour(T.Fbm(1.0, seed=3, octaves=1), p) == perlin(3, p)                                  # one octave is the Perlin of that seed
+    lac, pers = 2.0, 0.6
+    assert colour(T.Fbm(1.0, seed=0, octaves=2, lacunarity=lac, persistence=pers), p) == perlin(0, p) + perlin(1, p * lac) * pers
+    three = perlin(2, p * 0.5) + perlin(3, p * 0.5 * lac) * pers + perlin(4, p * 0.5 * lac * lac) * (pers * pers)
+    assert abs(colour(T.Fbm(0.5, seed=2, octaves=3, lacunarity=lac, persistence=pers), p) - three) < 1e-15       # scale multiplies the point first
+    assert colour(T.Turbulence(1.0, seed=4, power=0.0), p) == perlin(0, p)                            # no power: the source alone
+    u = 1.0 / 65536.0
+    off = np.array([[12414, 65124, 31337], [26519, 18128, 60493], [53820, 11213, 44845]]) * u
+    q = p + np.array([perlin(4 + c, p + off[c]) for c in range(3)]) * 0.75                             # roughness 1: each distortion is one Perlin
+    assert abs(colour(T.Turbulence(1.0, seed=4, roughness=1, power=0.75), p) - perlin(0, q)) < 1e-15
+    with pytest.raises(ValueError):
+        T.Fbm(1.0, octaves=0).build(be)
+    with pytest.raises(ValueError):
+        T.Fbm(1.0, octaves=33).build(_abi_backend())
+
+    # the flattened description: function and octaves in `odd`, consecutive tables from `resource` on, shared between functions
+    objects, background, _ = noise_kinds_scene()
+    sc = rt.Scene(objects, background)
+    d = sc.desc
+    noises = [d.textures[i] for i in range(d.n_textures) if d.textures[i].kind == 2]
+    assert sorted(t.odd & 255 for t in noises) == [_abi.RT_NOISE_PERLIN, _abi.RT_NOISE_FBM, _abi.RT_NOISE_FBM, _abi.RT_NOISE_TURBULENCE]
+    for t in noises:
+        fn, octaves = t.odd & 255, (t.odd >> 8) & 255
+        n_tables = {0: 1, 1: octaves, 2: octaves + 2}[fn]
+        assert t.resource + n_tables <= d.n_perm_tables
+        seed = {0: 0, 1: 0 if octaves == 6 else 2, 2: 5}[fn]
+        for k in range(n_tables):
+            buf = (C.c_uint8 * 256)()
+            lib.orc_perm_table(seed + k, buf)
+            assert bytes(d.perm_tables[256 * (t.resource + k):256 * (t.resource + k + 1)]) == bytes(buf)
+    assert d.n_perm_tables == 1 + 6 + 6                                # Perlin's, seeds 0..5, seeds 5..10; the Fbm of seeds 2..4 reuses the second run
+
+    # kernel code against the oracle: emitted colour of a light that wears each texture, at random points near the origin
+    texs = [T.Fbm(2.0), T.Turbulence(1.5, seed=5, roughness=4, power=0.75), T.Fbm(3.0, seed=2, octaves=3, lacunarity=2.0, persistence=0.6)]
+    sc2 = rt.Scene([rt.Object(rt.Shape.Sphere((3.0 * i, 0.0, 0.0), 1.0), rt.Material.DiffuseLight(t)) for i, t in enumerate(texs)], (0, 0, 0))
+    desc = sc2._host.rth_scene_desc(sc2._h)
+    rng = np.random.default_rng(21)
+    worst = 0.0
+    for i, t in enumerate(texs):
+        for pt in ((rng.random((300, 3)) * 2 - 1) * 6).astype(np.float32):
+            h32 = _abi.rt_hit(1, i, 1.0, (C.c_float * 3)(*pt), (C.c_float * 3)(0, 1, 0), (C.c_float * 3)(0, -1, 0), 0.0, 0.0)
+            s1, c1, o1, d1 = C.c_int32(), (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+            tw.twin_material_scatter(desc, C.byref(h32), 6, 0, 0, 0, C.byref(s1), c1, o1, d1)
+            ref = colour(t, pt.astype(np.float64))
+            assert s1.value == 0
+            worst = max(worst, abs(c1[0] - ref))
+    assert worst < 5e-5, worst
+
+
+def _abi_backend():
+    from raytracing_amd.api import host_backend
+    return host_backend()
