@@ -95,6 +95,10 @@ public:
     struct Node;
 
     static Shape Sphere(const Point3& center, double radius);
+    // NOT in the reference: a sphere that is also hit from within, at its far root (RT_PRIM_BOTH_ROOTS in rt_abi.h); for
+    // comparisons with the book the crate follows.
+    static Shape SphereBothRoots(const Point3& center, double radius);
+    Shape with_both_roots() const;  // this shape with every sphere in it made such a sphere (not the reference's behaviour either)
     static Shape sphere(double radius, std::pair<double, Point3> start, std::pair<double, Point3> end);  // shape.rs:222
     static Shape rectangle(const Point3& lower_left, const Point3& upper_right);                         // shape.rs:129
     static Shape new_box(const Point3& min, const Point3& max);                                          // shape.rs:157
@@ -171,6 +175,9 @@ public:
     static Material DiffuseLight(const Texture& emit);
     static Material Isotropic(const Texture& texture);
     static Material glass();  // materials.rs:21-26
+    // NOT in the reference: this material, handed the normal turned against the incoming ray (RT_MATF_FACE_NORMAL in rt_abi.h).
+    Material facing_normal() const { Material m = *this; m.face_normal = true; return m; }
+    bool face_normal = false;
     Kind kind;
     std::optional<Texture> texture;
     Vec3 albedo;
@@ -255,7 +262,8 @@ Example cornell();
 Example perlin();
 Example cornell_smoke();
 Example final_scene(Rng& rng, const textures::Texture& earthmap);
-Example by_name(const std::string& name, Rng& rng, const textures::Texture* earthmap);
+Example final_scene_book(Rng& rng, const textures::Texture& earthmap);  // NOT a reference example: final_scene from the book's camera, far-root spheres, facing normals
+Example by_name(const std::string& name, Rng& rng, const textures::Texture* earthmap);  // the five names above, or "final_scene_book"
 }  // namespace examples
 
 // lib.rs:68-72: x.max(0).min(1).sqrt() * 255.999 as u8 (saturating, NaN -> 0).

@@ -51,9 +51,13 @@ enum { RT_GEOM_SPHERE = 0, RT_GEOM_MOVING_SPHERE = 1, RT_GEOM_RECT = 2, RT_GEOM_
 enum {
     RT_PRIM_FLIP = 1u,   /* odd number of Shape::Flipped wrappers (outside the medium, if any) */
     RT_PRIM_MEDIUM = 2u, /* Shape::ConstantMedium { boundary, density } */
-    RT_PRIM_INERT = 4u   /* provably never hit (a medium whose boundary is a sphere: the second
+    RT_PRIM_INERT = 4u,  /* provably never hit (a medium whose boundary is a sphere: the second
                             boundary query of shape.rs:390 repeats the near root); kept in the
                             list so primitive ids stay stable, left out of the BVH */
+    RT_PRIM_BOTH_ROOTS = 8u /* NOT the reference's behaviour (a variant for comparison with the book the crate follows): a
+                            sphere whose near root lies outside the ray interval is tried at its far root as well, so a ray that
+                            starts inside a sphere hits it from within (glass refracts on the way out, a medium bounded by a
+                            sphere scatters).  shape.rs:262-271 only ever takes the near root */
 };
 
 typedef struct rt_prim {
@@ -112,8 +116,12 @@ typedef struct rt_material {
     uint32_t texture; /* Lambertian / DiffuseLight / Isotropic */
     float albedo[3];  /* Metal / Dielectric */
     float param;      /* Metal: fuzz; Dielectric: refraction_index */
-    uint32_t reserved[2];
+    uint32_t reserved[2]; /* [0]: 0 (the library keeps notes there on its own copy); [1]: RT_MATF_* */
 } rt_material; /* 32 bytes */
+/* NOT the reference's behaviour (a variant like RT_PRIM_BOTH_ROOTS): the material is handed the normal turned against the
+ * incoming ray, as the book's set_face_normal does; which face was hit (IntersectionPoint::face, shape.rs:552-558) is still
+ * decided on the shape's own normal.  The reference never flips (materials.rs:28-113 use p.normal as it comes). */
+#define RT_MATF_FACE_NORMAL 1u
 
 /* Texture (src/textures.rs:8-19). */
 enum { RT_TEX_SOLID = 0, RT_TEX_CHECKERED = 1, RT_TEX_NOISE = 2, RT_TEX_IMAGE = 3 };

@@ -226,6 +226,7 @@ struct Shape {
     enum Kind { Sphere, MovingSphere, Rectangle, ConstantMedium, Box, Flipped, Translated, Rotated } kind;
     // Sphere / MovingSphere
     Vec3 center{}; double radius = 0; Ray ray{}; double start_time = 0, end_time = 0;
+    bool both_roots = false;  // NOT the reference: try the far root when the near one is out of range (a variant for comparison)
     // Rectangle
     int axis = 0; double x0 = 0, y0 = 0, x1 = 0, y1 = 0, height = 0;
     // Box
@@ -307,6 +308,7 @@ bool Shape::intersect(const Ray& ray, double tmin, double tmax, double time, con
             double discriminant = half_b * half_b - a * c;
             if (discriminant < 0.0) { CNT(sphere_miss); return false; }
             double t = (-half_b - std::sqrt(discriminant)) / a;  // near root only
+            if (both_roots && !(t > tmin && t < tmax)) t = (-half_b + std::sqrt(discriminant)) / a;  // (the variant: then the far one)
             if (t > tmin && t < tmax) {
                 CNT(sphere_hit);
                 Vec3 point = ray.at(t);
@@ -324,7 +326,7 @@ bool Shape::intersect(const Ray& ray, double tmin, double tmax, double time, con
         }
         case MovingSphere: {  // shape.rs:295-307
             CNT(moving);
-            Shape s; s.kind = Sphere; s.center = this->ray.at(time - start_time); s.radius = radius;
+            Shape s; s.kind = Sphere; s.center = this->ray.at(time - start_time); s.radius = radius; s.both_roots = both_roots;
             return s.intersect(ray, tmin, tmax, time, ctx, prim, out);
         }
         case Rectangle: {  // shape.rs:309-344
@@ -576,8 +578,12 @@ static inline double schlick(double cosine, double refraction_index) {  // mater
 struct Material {
     enum Kind { Lambertian, Metal, Dielectric, DiffuseLight, Isotropic } kind;
     TexP texture; Vec3 albedo{}; double param = 0;  // fuzz | refraction_index
-    RayHit scatter(const IntersectionPoint& p, const DrawCtx& ctx) const {
+    bool face_normal = false;  // NOT the reference: the material sees the normal turned against the incoming ray (a variant for comparison)
+    RayHit scatter(const IntersectionPoint& p_in, const DrawCtx& ctx) const {
         U4 r = ctx.draw(ctx.bounce, 0);
+        const bool front = p_in.front_face();
+        IntersectionPoint p = p_in;
+        if (face_normal && !front) p.normal = -p.normal;
         switch (kind) {
             case Lambertian: {  // materials.rs:30-47, :116-129
                 CNT(lambertian);
@@ -598,7 +604,7 @@ struct Material {
             }
             case Dielectric: {  // materials.rs:65-93
                 CNT(dielectric);
-                double eta_ratio = p.front_face() ? 1.0 / param : param;
+                double eta_ratio = front ? 1.0 / param : param;
                 Vec3 in_unit = normed(p.in_vec);
                 double cos_theta = -rmin(dot(in_unit, p.normal), 1.0);
                 double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
@@ -962,6 +968,10 @@ struct orc_camera_options { double aperture, aspect_ratio, focus_distance, looki
 static Vec3 v3(const double* p) { return V(p[0], p[1], p[2]); }
 
 void* orc_sphere(const double* c, double r) { return new ShapeP(make_sphere(v3(c), r)); }
+void* orc_sphere_both_roots(const double* c, double r) {
+    auto s = std::make_shared<Shape>(); s->kind = Shape::Sphere; s->center = v3(c); s->radius = r; s->both_roots = true;
+    return new ShapeP(s);
+}
 void* orc_sphere_timed(double r, double t0, const double* c0, double t1, const double* c1) {
     ShapeP s = make_sphere_timed(r, t0, v3(c0), t1, v3(c1));
     return s ? new ShapeP(s) : nullptr;
@@ -1003,6 +1013,7 @@ void* orc_mat_metal(const double* a, double fuzz) { return new MatP(mat_metal(v3
 void* orc_mat_dielectric(const double* a, double ri) { return new MatP(mat_dielectric(v3(a), ri)); }
 void* orc_mat_diffuse_light(void* t) { return new MatP(mat_light(*(TexP*)t)); }
 void* orc_mat_isotropic(void* t) { return new MatP(mat_isotropic(*(TexP*)t)); }
+void* orc_mat_face_normal(void* m) { auto c = std::make_shared<Material>(**(MatP*)m); c->face_normal = true; return new MatP(c); }
 void orc_mat_free(void* m) { delete (MatP*)m; }
 
 void orc_perm_table(uint32_t seed, uint8_t* out256) { PermTable pt = perm_table_from_seed(seed); std::memcpy(out256, pt.values, 256); }

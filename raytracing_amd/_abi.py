@@ -14,7 +14,8 @@ RT_OK = 0
 RT_ERR_INVALID_ARGUMENT, RT_ERR_EMPTY_SCENE, RT_ERR_UNSUPPORTED, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OUT_OF_MEMORY = 1, 2, 3, 4, 5, 6
 RT_RENDER_PROFILE, RT_RENDER_NO_TAIL, RT_RENDER_TAIL_ONLY, RT_RENDER_NODES_IN_GLOBAL, RT_RENDER_ONE_STREAM, RT_RENDER_RECALIBRATE, RT_RENDER_ONE_KERNEL, RT_RENDER_TWO_KERNELS = 1, 2, 4, 8, 16, 32, 64, 128
 RT_GEOM_SPHERE, RT_GEOM_MOVING_SPHERE, RT_GEOM_RECT, RT_GEOM_BOX = 0, 1, 2, 3
-RT_PRIM_FLIP, RT_PRIM_MEDIUM, RT_PRIM_INERT = 1, 2, 4
+RT_PRIM_FLIP, RT_PRIM_MEDIUM, RT_PRIM_INERT, RT_PRIM_BOTH_ROOTS = 1, 2, 4, 8
+RT_MATF_FACE_NORMAL = 1
 RT_BVH_NONE, RT_BVH_EXACT = 0xFFFFFFFF, 0x80000000
 RT_NOISE_PERLIN, RT_NOISE_FBM, RT_NOISE_TURBULENCE = 0, 1, 2
 RT_K_NAMES = ("raygen", "traverse", "shade", "tail", "resolve", "finalize")
@@ -133,6 +134,7 @@ def builder_symbols(prefix):
     (prefix 'rth_') and the test oracle (prefix 'orc_')."""
     return {
         prefix + "sphere": (_P, [_D3, C.c_double]),
+        prefix + "sphere_both_roots": (_P, [_D3, C.c_double]),
         prefix + "sphere_timed": (_P, [C.c_double, C.c_double, _D3, C.c_double, _D3]),
         prefix + "rectangle": (_P, [_D3, _D3]),
         prefix + "new_box": (_P, [_D3, _D3]),
@@ -154,6 +156,7 @@ def builder_symbols(prefix):
         prefix + "mat_dielectric": (_P, [_D3, C.c_double]),
         prefix + "mat_diffuse_light": (_P, [_P]),
         prefix + "mat_isotropic": (_P, [_P]),
+        prefix + "mat_face_normal": (_P, [_P]),
         prefix + "mat_free": (None, [_P]),
         prefix + "perm_table": (None, [C.c_uint32, C.c_void_p]),
         prefix + "scene_free": (None, [_P]),

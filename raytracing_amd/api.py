@@ -44,8 +44,9 @@ class Shape:
 
     # constructors named as in the reference
     @staticmethod
-    def Sphere(center, radius):
-        return Shape("sphere", center=tuple(center), radius=float(radius))
+    def Sphere(center, radius, both_roots=False):
+        """`both_roots` is NOT the reference's behaviour: the sphere is also hit from within, at its far root (RT_PRIM_BOTH_ROOTS)."""
+        return Shape("sphere", center=tuple(center), radius=float(radius), both_roots=bool(both_roots))
 
     @staticmethod
     def sphere(radius, start: Tuple[float, Sequence[float]], end: Tuple[float, Sequence[float]]):
@@ -81,7 +82,7 @@ class Shape:
         """Instantiates the tree in a library; returns an owned handle (free with be.shape_free)."""
         k, kw = self.kind, self.kw
         if k == "sphere":
-            return be.sphere(_d3(kw["center"]), kw["radius"])
+            return (be.sphere_both_roots if kw.get("both_roots") else be.sphere)(_d3(kw["center"]), kw["radius"])
         if k == "sphere_timed":
             h = be.sphere_timed(kw["radius"], kw["t0"], _d3(kw["c0"]), kw["t1"], _d3(kw["c1"]))
             if not h:
@@ -217,7 +218,20 @@ class Material:
     def glass():
         return Material.Dielectric((1.0, 1.0, 1.0), 1.5)
 
+    def facing_normal(self):
+        """NOT the reference's behaviour: this material, handed the normal turned against the incoming ray (RT_MATF_FACE_NORMAL)."""
+        m = Material(self.kind, self.texture, self.albedo, self.param)
+        m.face_normal = True
+        return m
+
     def build(self, be: Backend):
+        m = self._build(be)
+        if getattr(self, "face_normal", False):
+            plain, m = m, be.mat_face_normal(m)
+            be.mat_free(plain)
+        return m
+
+    def _build(self, be: Backend):
         if self.kind in ("lambertian", "diffuse_light", "isotropic"):
             t = self.texture.build(be)
             try:

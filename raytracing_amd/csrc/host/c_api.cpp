@@ -31,6 +31,7 @@ extern "C" {
 const char* rth_last_error(void) { return g_err.c_str(); }
 
 void* rth_sphere(const double* c, double r) { return new Shape(Shape::Sphere(p3(c), r)); }
+void* rth_sphere_both_roots(const double* c, double r) { return new Shape(Shape::SphereBothRoots(p3(c), r)); }
 void* rth_sphere_timed(double r, double t0, const double* c0, double t1, const double* c1) {
     try { return new Shape(Shape::sphere(r, {t0, p3(c0)}, {t1, p3(c1)})); } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
 }
@@ -69,6 +70,7 @@ void* rth_tex_image_file(const char* path) {
 }
 void rth_tex_free(void* t) { delete (Texture*)t; }
 
+void* rth_mat_face_normal(void* m) { return new Material(((Material*)m)->facing_normal()); }
 void* rth_mat_lambertian(void* t) { return new Material(Material::Lambertian(*(Texture*)t)); }
 void* rth_mat_metal(const double* a, double fuzz) { return new Material(Material::Metal(v3(a), fuzz)); }
 void* rth_mat_dielectric(const double* a, double ri) { return new Material(Material::Dielectric(v3(a), ri)); }

@@ -59,6 +59,7 @@ BoundingBox operator+(const BoundingBox& a, const BoundingBox& b) {
 struct Shape::Node {
     Kind kind;
     Point3 center; double radius = 0;                 // Sphere; MovingSphere: center = ray.origin
+    bool both_roots = false;                          // Sphere: the far-root variant (not the reference's)
     Vec3 motion; double start_time = 0, end_time = 0; // MovingSphere: ray.direction
     Axis axis = Axis::X; double x0 = 0, y0 = 0, x1 = 0, y1 = 0, height = 0;  // Rectangle; Rotated uses axis
     Point3 bmin, bmax;                                // Box
@@ -78,6 +79,17 @@ Shape Shape::Sphere(const Point3& center, double radius) {
     auto n = std::make_shared<Node>(); n->kind = Kind::Sphere; n->center = center; n->radius = radius;
     return Shape(n);
 }
+Shape Shape::SphereBothRoots(const Point3& center, double radius) {
+    auto n = std::make_shared<Node>(); n->kind = Kind::Sphere; n->center = center; n->radius = radius; n->both_roots = true;
+    return Shape(n);
+}
+static std::shared_ptr<const Shape::Node> both_roots_copy(const std::shared_ptr<const Shape::Node>& n) {
+    auto c = std::make_shared<Shape::Node>(*n);
+    if (c->kind == Shape::Kind::Sphere || c->kind == Shape::Kind::MovingSphere) c->both_roots = true;
+    if (c->inner) c->inner = both_roots_copy(c->inner);
+    return c;
+}
+Shape Shape::with_both_roots() const { return Shape(both_roots_copy(n_)); }
 Shape Shape::sphere(double radius, std::pair<double, Point3> start, std::pair<double, Point3> end) {
     if (!(end.first > start.first)) throw std::invalid_argument("Shape::sphere: end_time must be greater than start_time");
     if (start.second == end.second) return Sphere(start.second, radius);
@@ -407,7 +419,8 @@ void Scene::Impl::add_object(const Object& obj) {
             P.geom_index = (uint32_t)spheres.size(); spheres.push_back(s);
             // A medium bounded by a sphere can never be hit: the second boundary query
             // (shape.rs:390) recomputes the same near root, which is not > t + 0.001.
-            if (medium) P.flags |= RT_PRIM_INERT;
+            if (cur->both_roots) P.flags |= RT_PRIM_BOTH_ROOTS;
+            else if (medium) P.flags |= RT_PRIM_INERT;
             break;
         }
         case K::Rectangle: {
@@ -430,6 +443,7 @@ void Scene::Impl::add_object(const Object& obj) {
     if (m.texture) M.texture = add_texture(m.texture->node());
     for (int c = 0; c < 3; ++c) M.albedo[c] = (float)m.albedo[c];
     M.param = (float)m.param;
+    if (m.face_normal) M.reserved[1] |= RT_MATF_FACE_NORMAL;
     uint32_t mi = UINT32_MAX;
     for (uint32_t k = 0; k < materials.size(); ++k) if (std::memcmp(&materials[k], &M, sizeof(M)) == 0) { mi = k; break; }
     if (mi == UINT32_MAX) { mi = (uint32_t)materials.size(); materials.push_back(M); }
@@ -763,14 +777,28 @@ Example final_scene(Rng& rng, const Texture& earthmap) {
     e.background = Vec3(1, 1, 1);
     return e;
 }
+// NOT one of the reference's examples: final_scene as the book the crate follows shows it -- seen from (478, 278, -600)
+// towards (278, 278, 0) with a 40 degree field of view and a pinhole lens, every sphere also hit from within
+// (RT_PRIM_BOTH_ROOTS: the glass balls refract on the way out, the two balls of smoke scatter) and every material handed the
+// normal turned against the ray (RT_MATF_FACE_NORMAL).  Objects, sizes, colours and random draws are final_scene's own.  For
+// comparison pictures; no parity claim hangs on it.
+Example final_scene_book(Rng& rng, const Texture& earthmap) {
+    Example e = final_scene(rng, earthmap);
+    e.camera = CameraOptions{0.0, 1.0, 10.0, Point3(278, 278, 0), Point3(478, 278, -600), 1.0, 0.0, 40.0, Vec3(0, 1, 0)};
+    for (Object& o : e.objects) {
+        o.shape = o.shape.with_both_roots();
+        o.material = o.material.facing_normal();
+    }
+    return e;
+}
 Example by_name(const std::string& name, Rng& rng, const Texture* earthmap) {
     if (name == "random_spheres") return random_spheres(rng);
     if (name == "cornell") return cornell();
     if (name == "perlin") return perlin();
     if (name == "cornell_smoke") return cornell_smoke();
-    if (name == "final_scene") {
+    if (name == "final_scene" || name == "final_scene_book") {
         if (!earthmap) throw std::invalid_argument("final_scene needs the earth map texture");
-        return final_scene(rng, *earthmap);
+        return name == "final_scene" ? final_scene(rng, *earthmap) : final_scene_book(rng, *earthmap);
     }
     throw std::invalid_argument("unknown example scene: " + name);
 }

@@ -287,6 +287,14 @@ RT_HD bool sphere_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time
     return true;
 }
 
+// The far root (-half_b + sqrt(disc)) / a, for spheres flagged RT_PRIM_BOTH_ROOTS (not the reference's behaviour); the
+// discriminant is known not to be negative.
+RT_HD double sphere_far_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, float time) {
+    D3 oc = o - sphere_center(sp, moving, time);
+    double a = dot(dd, dd), half_b = dot(oc, dd), cc = dot(oc, oc) - sp.radius * sp.radius;
+    return (-half_b + sqrt_near(half_b * half_b - a * cc)) * rcp_near(a);
+}
+
 // Rectangle (shape.rs:309-332): inclusive interval and extents tests written so that NaN and
 // infinity flow exactly as in the reference.
 // `height_lo`: the remainder of the plane's coordinate (fp32 callers; the f64 callers pass the whole coordinate as `height`).
@@ -397,7 +405,11 @@ RT_HD bool geom_t(const SceneView& S, const rt_prim& P, VT o, VT d, T tmin, T tm
     if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
         double t64;
         if (!sphere_root(S.spheres[P.geom_index], P.geom == RT_GEOM_MOVING_SPHERE, d3(o), d3(d), time, t64)) return false;
-        if (!(t64 > (double)tmin && t64 < (double)tmax)) return false;  // strict on both ends (shape.rs:271)
+        if (!(t64 > (double)tmin && t64 < (double)tmax)) {  // strict on both ends (shape.rs:271)
+            if (!(P.flags & RT_PRIM_BOTH_ROOTS)) return false;
+            t64 = sphere_far_root(S.spheres[P.geom_index], P.geom == RT_GEOM_MOVING_SPHERE, d3(o), d3(d), time);  // (the variant: then the far root)
+            if (!(t64 > (double)tmin && t64 < (double)tmax)) return false;
+        }
         t = (T)t64;
         return true;
     }
@@ -462,6 +474,10 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
         const bool moving = P.geom == RT_GEOM_MOVING_SPHERE;
         double t64 = (double)t;
         sphere_root(sp, moving, o, d, time, t64);
+        if (P.flags & RT_PRIM_BOTH_ROOTS) {  // the accepted t is the fp32 rounding of one of the two roots
+            const double far_root = sphere_far_root(sp, moving, o, d, time);
+            if (fabs(far_root - (double)t) < fabs(t64 - (double)t)) t64 = far_root;
+        }
         const D3 c = sphere_center(sp, moving, time);
         const D3 p = ray_at(o, d, t64);
         const D3 pc = p - c;
@@ -748,7 +764,7 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
     auto plain_sphere = [&](const rt_bvh_node& N) {
         if (N.prim == RT_BVH_NONE) return false;
         const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
-        return Pp.geom == RT_GEOM_SPHERE && !(Pp.flags & RT_PRIM_MEDIUM);
+        return Pp.geom == RT_GEOM_SPHERE && !(Pp.flags & (RT_PRIM_MEDIUM | RT_PRIM_BOTH_ROOTS));  // (the far-root variant takes the general test)
     };
     auto plain_box = [&](const rt_bvh_node& N) {  // exact leaf of an unwrapped box whose box is the leaf's box (rounded to fp32)
         if (N.prim == RT_BVH_NONE || !(N.prim & RT_BVH_EXACT)) return false;
@@ -1151,8 +1167,14 @@ RT_HD V3 material_color(const SceneView& S, const rt_material& M, const Hit& h) 
 }
 
 // Material::scatter (materials.rs:28-114) with the draws of stream 0 of the segment.
-RT_HD Scatter material_scatter(const SceneView& S, const rt_material& M, const Hit& h, const DrawKey& key) {
+RT_HD Scatter material_scatter(const SceneView& S, const rt_material& M, const Hit& h_in, const DrawKey& key) {
     const U4 rnd = philox4x32_10(key.pixel, key.sample, key.bounce, 0u, key.k0, key.k1);
+    Hit h = h_in;
+    bool front = true;  // IntersectionPoint::face (shape.rs:552-558); only the dielectric asks
+    if (M.kind == RT_MAT_DIELECTRIC) front = dot(h.in_vec, h.normal) < 0.0f;
+    if (M.reserved[1] & RT_MATF_FACE_NORMAL) {  // (not the reference: the normal turned against the incoming ray; in_vec may be unnormalised here, its sign is what counts)
+        if (!(dot(h.in_vec, h.normal) < 0.0f)) h.normal = -h.normal;
+    }
     Scatter out;
     out.o = h.point;
     out.d = v3(0.0f, 0.0f, 0.0f);
@@ -1175,7 +1197,6 @@ RT_HD Scatter material_scatter(const SceneView& S, const rt_material& M, const H
         if (dot(s, h.normal) >= 0.0f) { out.scattered = true; out.color = v3(M.albedo[0], M.albedo[1], M.albedo[2]); out.d = s; }
         else { out.scattered = false; out.color = v3(0.0f, 0.0f, 0.0f); }
     } else if (M.kind == RT_MAT_DIELECTRIC) {
-        bool front = dot(h.in_vec, h.normal) < 0.0f;  // shape.rs:554
         float eta = front ? 1.0f / M.param : M.param;
         V3 in_unit = normed(h.in_vec);
         float cos_theta = -fminf(dot(in_unit, h.normal), 1.0f);

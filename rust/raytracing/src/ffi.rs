@@ -13,6 +13,12 @@ pub const RT_GEOM_BOX: u8 = 3;
 pub const RT_PRIM_FLIP: u8 = 1;
 pub const RT_PRIM_MEDIUM: u8 = 2;
 pub const RT_PRIM_INERT: u8 = 4;
+pub const RT_PRIM_BOTH_ROOTS: u8 = 8; // not the reference's behaviour; the facade never sets it
+pub const RT_MATF_FACE_NORMAL: u32 = 1; // likewise (rt_material.reserved[1])
+
+pub const RT_NOISE_PERLIN: u32 = 0;
+pub const RT_NOISE_FBM: u32 = 1;
+pub const RT_NOISE_TURBULENCE: u32 = 2;
 
 pub const RT_XF_TRANSLATE: u32 = 0;
 pub const RT_XF_ROTATE_X: u32 = 1;

@@ -34,6 +34,10 @@ def shape_zoo():
         ("medium_cube", S.ConstantMedium(S.new_box((-2, -2, -2), (2, 2, 2)), 0.4)),
         ("medium_sphere", S.ConstantMedium(S.Sphere((0, 0, 0), 3.0), 0.5)),  # never hit (near root twice)
         ("medium_wrapped", S.ConstantMedium(S.new_box((-1, -1, -1), (1, 1, 1)).rotated(rt.AXIS_Z, 30.0), 0.8).rotated(rt.AXIS_X, 20.0).translated((1, 2, 3)).flipped()),
+        # the far-root variant (RT_PRIM_BOTH_ROOTS; not the reference's behaviour): hit from within as well, and a medium inside one scatters
+        ("sphere_both_roots", S.Sphere((1.0, 2.0, -3.0), 2.5, both_roots=True)),
+        ("sphere_both_roots_rot_y_trans", S.Sphere((0, 0, 0), 2.0, both_roots=True).rotate(rt.AXIS_Y, 45.0).translated((1, -1, 2))),
+        ("medium_sphere_both_roots", S.ConstantMedium(S.Sphere((0, 0, 0), 3.0, both_roots=True), 0.5)),
     ]
 
 
@@ -167,5 +171,22 @@ def noise_kinds_scene():
         rt.Object(S.Sphere((2.2, 1.0, 0.0), 1.0), M.DiffuseLight(T.Checkered(T.Fbm(3.0, seed=2, octaves=3, lacunarity=2.0, persistence=0.6), T.SolidColor((0.9, 0.8, 0.7))))),
     ]
     co = dict(aperture=0.0, aspect_ratio=1.5, focus_distance=10.0, looking_at=(0.0, 1.0, 0.0), origin=(0.0, 2.5, 9.0), shutter_close=1.0, shutter_open=0.0,
+              vfov=30.0, vup=(0.0, 1.0, 0.0))
+    return objects, (0.7, 0.8, 1.0), co
+
+
+def far_root_variant_scene():
+    """A scene built from the variants that are NOT the reference's behaviour (RT_PRIM_BOTH_ROOTS spheres, RT_MATF_FACE_NORMAL
+    materials): a glass ball that refracts on the way out, a ball of smoke, a matt ball and a floor, under a sky."""
+    import raytracing_amd as rt
+    T, M, S = rt.Texture, rt.Material, rt.Shape
+    objects = [
+        rt.Object(S.Sphere((0.0, -100.0, 0.0), 100.0, both_roots=True), M.Lambertian(T.Checkered(T.SolidColor((0.2, 0.3, 0.1)), T.SolidColor((0.9, 0.9, 0.9)))).facing_normal()),
+        rt.Object(S.Sphere((-2.2, 1.0, 0.0), 1.0, both_roots=True), M.glass().facing_normal()),
+        rt.Object(S.ConstantMedium(S.Sphere((0.0, 1.0, 0.0), 1.0, both_roots=True), 1.5), M.Isotropic(T.SolidColor((0.9, 0.5, 0.3)))),
+        rt.Object(S.Sphere((2.2, 1.0, 0.0), 1.0, both_roots=True), M.Lambertian(T.SolidColor((0.4, 0.2, 0.6))).facing_normal()),
+        rt.Object(S.Sphere((0.0, 1.0, -2.5), 1.0, both_roots=True), M.Metal((0.8, 0.8, 0.8), 0.1).facing_normal()),
+    ]
+    co = dict(aperture=0.05, aspect_ratio=1.5, focus_distance=9.0, looking_at=(0.0, 1.0, 0.0), origin=(0.0, 2.0, 9.0), shutter_close=1.0, shutter_open=0.0,
               vfov=30.0, vup=(0.0, 1.0, 0.0))
     return objects, (0.7, 0.8, 1.0), co

@@ -564,3 +564,21 @@ def test_noise_kinds_fbm_and_turbulence():
 def _abi_backend():
     from raytracing_amd.api import host_backend
     return host_backend()
+
+
+def test_final_scene_book_variant_flattens_with_the_switches(earth):
+    """final_scene_book (not a reference example): final_scene's objects with every sphere a far-root sphere, every material with the
+    facing normal, the book's camera; the media bounded by spheres are no longer inert and stand in the tree."""
+    a, _ = rt.Scene.example("final_scene", 1, earth)
+    b, co = rt.Scene.example("final_scene_book", 1, earth)
+    da, db = a.desc, b.desc
+    assert db.n_prims == da.n_prims == 1410 and tuple(co.origin) == (478.0, 278.0, -600.0) and co.vfov == 40.0 and co.aperture == 0.0
+    for i in range(db.n_prims):
+        pa, pb = da.prims[i], db.prims[i]
+        assert pb.geom == pa.geom and pb.geom_index == pa.geom_index
+        sphere = pb.geom in (_abi.RT_GEOM_SPHERE, _abi.RT_GEOM_MOVING_SPHERE)
+        assert bool(pb.flags & _abi.RT_PRIM_BOTH_ROOTS) == sphere and not (pb.flags & _abi.RT_PRIM_INERT)
+        assert db.materials[pb.material].reserved[1] == _abi.RT_MATF_FACE_NORMAL and da.materials[pa.material].reserved[1] == 0
+    assert sum(1 for i in range(da.n_prims) if da.prims[i].flags & _abi.RT_PRIM_INERT) == 2
+    leaves = lambda d: sum(1 for k in range(d.n_bvh_nodes) if d.bvh[k].prim != _abi.RT_BVH_NONE)
+    assert leaves(db) == 1410 and leaves(da) == 1408

@@ -348,3 +348,48 @@ def test_converged_fixtures_are_what_the_oracle_renders(earth):
         blocks = lambda x: x[:h // 8 * 8, :w // 8 * 8].reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
         pix, blk = np.sqrt(((a - b) ** 2).mean()), np.sqrt(((blocks(a) - blocks(b)) ** 2).mean())
         assert 0 < blk < 0.25 * pix, (name, pix, blk)
+
+
+def test_far_root_and_facing_normal_variants_by_hand():
+    """The two switches that are NOT the reference's behaviour (RT_PRIM_BOTH_ROOTS, RT_MATF_FACE_NORMAL), on cases worked by hand.
+    The reference takes a sphere's near root only (shape.rs:262-271) and never turns a normal (materials.rs:28-113)."""
+    S, M, T = rt.Shape, rt.Material, rt.Texture
+    t0 = [0.0]
+    plain, both = OracleShape(S.Sphere((0, 0, 0), 2.0)), OracleShape(S.Sphere((0, 0, 0), 2.0, both_roots=True))
+    # from the centre along +x: near root -2 is behind the ray; the variant takes the far root 2, the reference nothing
+    assert plain.intersect([[0, 0, 0]], [[1.0, 0, 0]], t0, 0.001, INF)[0]["hit"] == 0
+    h = both.intersect([[0, 0, 0]], [[1.0, 0, 0]], t0, 0.001, INF)[0]
+    assert h["hit"] == 1 and h["t"] == 2.0 and list(h["point"]) == [2, 0, 0] and list(h["normal"]) == [1, 0, 0]     # the normal stays outward
+    # from outside both take the near root; with the interval starting behind it the variant moves on to the far one
+    for sh in (plain, both):
+        h = sh.intersect([[-5, 0, 0]], [[1.0, 0, 0]], t0, 0.001, INF)[0]
+        assert h["hit"] == 1 and h["t"] == 3.0
+    assert plain.intersect([[-5, 0, 0]], [[1.0, 0, 0]], t0, 3.5, INF)[0]["hit"] == 0
+    assert both.intersect([[-5, 0, 0]], [[1.0, 0, 0]], t0, 3.5, INF)[0]["t"] == 7.0
+    assert both.intersect([[-5, 0, 0]], [[1.0, 0, 0]], t0, 3.5, 6.0)[0]["hit"] == 0
+    # a medium inside such a sphere: ip1 = near root 3, ip2 = far root 7 (shape.rs:386-410 as written), free flight -ln(u) / density
+    smoke = OracleShape(S.ConstantMedium(S.Sphere((0, 0, 0), 2.0, both_roots=True), 0.5))
+    u = 0.5
+    h = smoke.intersect([[-5, 0, 0]], [[1.0, 0, 0]], t0, 0.001, INF, medium_u=[u])[0]
+    assert h["hit"] == 1 and abs(h["t"] - (3.0 - np.log(u) / 0.5)) < 1e-12
+    assert smoke.intersect([[-5, 0, 0]], [[1.0, 0, 0]], t0, 0.001, INF, medium_u=[0.1])[0]["hit"] == 0          # flight 4.6 > 4 inside
+    h = smoke.intersect([[0, 0, 0]], [[1.0, 0, 0]], t0, 0.001, INF, medium_u=[u])[0]                           # from within: ip1 = -2, ip2 = 2
+    assert h["hit"] == 1 and abs(h["t"] - (0.001 - np.log(u) / 0.5)) < 1e-12                                  # t1 = max(ip1, tmin) (shape.rs:396)
+    # glass with the facing normal, left from within head-on: back face, eta = 1.5, the normal turned to (-1, 0, 0), cos = 1,
+    # both branches keep the axis: refracted (in + n cos) eta - n = (1, 0, 0), reflected (-1, 0, 0); never the reference's
+    # refraction back into the ball
+    ball = S.Sphere((0, 0, 0), 2.0, both_roots=True)
+    outward = 0
+    for sample in range(16):
+        h, sc, col, ro, rd = _oracle_scatter(ball, M.glass().facing_normal(), [0, 0, 0], [1.0, 0, 0], key=(3, sample, 0))
+        assert sc == 1 and list(ro) == [2, 0, 0] and rd[1] == 0 and rd[2] == 0 and abs(abs(rd[0]) - 1.0) < 1e-15
+        outward += rd[0] > 0
+    assert outward >= 12                                                                                       # schlick(1, 1.5) = 0.04
+    # Lambertian below a floor: the reference scatters through the surface (about +y), the facing normal back down
+    floor = S.rectangle((-5, 0, -5), (5, 0, 5))
+    for sample in range(8):
+        _, _, _, _, rd = _oracle_scatter(floor, M.Lambertian(T.SolidColor((0.5, 0.5, 0.5))).facing_normal(), [-2, -2, 0], [1.0, 1.0, 0.0], key=(9, sample, 2))
+        assert rd[1] < 0 and abs(np.linalg.norm(rd - [0, -1, 0]) - 1.0) < 1e-12
+    # Metal from below: mirrored about the turned normal and kept (the reference ends the path black there)
+    _, sc, col, _, rd = _oracle_scatter(floor, M.Metal((0.8, 0.6, 0.2), 0.0).facing_normal(), [-2, -2, 0], [1.0, 1.0, 0.0])
+    assert sc == 1 and np.allclose(rd, [np.sqrt(0.5), -np.sqrt(0.5), 0], atol=1e-15)
