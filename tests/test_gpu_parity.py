@@ -567,3 +567,21 @@ def test_far_root_and_facing_normal_variants():
         ob.material = rt.Material(ob.material.kind, ob.material.texture, ob.material.albedo, ob.material.param)
     _, ref_mean = rt.Scene(objects, background).render(cam, rt.ImageOptions(h, w, spp, 50), rt.RenderOptions(seed=1), want_mean=True)
     assert rmse(np.clip(ref_mean, 0, 1) * 255, np.clip(mean, 0, 1) * 255) > 5.0   # grey levels, on the linear means
+
+
+def test_final_scene_book_variant_renders(earth):
+    """final_scene_book (not a reference example; its switches are tested against the oracle above): renders, finite, the same
+    bytes whatever the kernel split, and its two balls of smoke, inert in the reference's scene, are hit."""
+    sc, co = rt.Scene.example("final_scene_book", 1, earth)
+    cam = rt.Camera(co)
+    io = rt.ImageOptions(64, 64, 8, 50)
+    _, base = sc.render(cam, io, rt.RenderOptions(seed=2), want_mean=True)
+    assert np.isfinite(base).all() and base.mean() > 0.01
+    for flags in (_abi.RT_RENDER_NO_TAIL, _abi.RT_RENDER_TAIL_ONLY, _abi.RT_RENDER_NODES_IN_GLOBAL):
+        assert np.array_equal(sc.render(cam, io, rt.RenderOptions(seed=2, flags=flags), want_mean=True)[1], base)
+    rng = np.random.default_rng(5)
+    rays = sc.camera_rays(cam, io, 2, rng.integers(0, 64, 4000), rng.integers(0, 64, 4000), rng.integers(0, 8, 4000))
+    hits = sc.intersect_batch(rays[:, 0:3], rays[:, 3:6], rays[:, 6], seed=3)
+    d = sc.desc
+    media = {i for i in range(d.n_prims) if d.prims[i].flags & _abi.RT_PRIM_MEDIUM}
+    assert len(media) == 2 and media & set(int(p) for p in hits["prim"][hits["hit"] == 1])
