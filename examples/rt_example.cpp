@@ -3,7 +3,7 @@
 // write the image.  Defaults are each example's own constants (image size, 100 samples per pixel, 50 reflections,
 // output "test.png"); everything can be overridden on the command line.
 //
-//   rt_example <random_spheres|cornell|perlin|cornell_smoke|final_scene>
+//   rt_example <random_spheres|cornell|perlin|cornell_smoke|final_scene|final_scene_book>
 //              [--width W] [--height H] [--spp N] [--depth N] [--seed S] [--scene-seed S]
 //              [--gpus N | --devices a,b,c] [--earthmap file.ppm] [--out file.png|file.ppm]
 #include <chrono>
@@ -23,11 +23,12 @@ struct Defaults { const char* name; uint32_t width; double aspect; };
 // IMAGE_WIDTH / ASPECT_RATIO of the examples (random_spheres.rs:10-11, cornell.rs:9-10, perlin.rs:11-12,
 // cornell_smoke.rs:9-10, final_scene.rs:10-11)
 const Defaults kDefaults[] = {{"random_spheres", 640, 16.0 / 9.0}, {"cornell", 750, 1.0}, {"perlin", 1280, 16.0 / 9.0},
-                              {"cornell_smoke", 750, 1.0}, {"final_scene", 500, 1.0}};
+                              {"cornell_smoke", 750, 1.0}, {"final_scene", 500, 1.0},
+                              {"final_scene_book", 500, 1.0}};  // (the last is not a reference example: see examples::final_scene_book)
 
 int usage(const char* argv0) {
     std::fprintf(stderr,
-                 "usage: %s <random_spheres|cornell|perlin|cornell_smoke|final_scene> [--width W] [--height H] [--spp N] [--depth N]\n"
+                 "usage: %s <random_spheres|cornell|perlin|cornell_smoke|final_scene|final_scene_book> [--width W] [--height H] [--spp N] [--depth N]\n"
                  "          [--seed S] [--scene-seed S] [--gpus N | --devices a,b,c] [--earthmap file.ppm] [--out file.png|file.ppm]\n",
                  argv0);
     return 2;
@@ -64,7 +65,7 @@ int main(int argc, char** argv) {
     try {
         Rng rng(scene_seed);
         textures::Texture earth = textures::Texture::SolidColor(geometry::Vec3{0.5, 0.5, 0.5});
-        if (name == "final_scene") earth = textures::Texture::image(earthmap);
+        if (name == "final_scene" || name == "final_scene_book") earth = textures::Texture::image(earthmap);
         examples::Example ex = examples::by_name(name, rng, &earth);
         const size_t n_objects = ex.objects.size();
         Scene scene(std::move(ex.objects), ex.background, rng);
