@@ -47,7 +47,12 @@ def gather_frames(local_mean: torch.Tensor, dst: int = 0, group=None) -> torch.T
     """Sum-reduce of the per-rank frames (zeros outside the owned tiles) to `dst`; in place."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if local_mean.is_cuda and dist.get_backend(group) == "gloo":
-            dist.all_reduce(local_mean, op=dist.ReduceOp.SUM, group=group)  # gloo has no reduce() for device tensors (rehearsals only)
+            # rehearsals only (several ranks on one GPU, no RCCL): through the host -- gloo's own handling of device tensors
+            # hung on the second collective of a process on this ROCm build
+            host = local_mean.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            if dist.get_rank(group) == dst:
+                local_mean.copy_(host)
         else:
             dist.reduce(local_mean, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return local_mean
