@@ -240,8 +240,10 @@ enum {
     RT_RENDER_ONE_STREAM = 16u, /* never split a pass into two halves on two streams (same image; for tests and clean kernel timings) */
     RT_RENDER_ONE_KERNEL = 64u,  /* walk and shade a bounce in one kernel whatever the tree's size (same image; for tests) */
     RT_RENDER_TWO_KERNELS = 128u,/* never do that: every bounce as a traversal launch and a shading launch (same image; for tests) */
-    RT_RENDER_RECALIBRATE = 32u /* measure the frame's schedule again (where the tail kernel takes over, whether two streams
+    RT_RENDER_RECALIBRATE = 32u, /* measure the frame's schedule again (where the tail kernel takes over, whether two streams
                                    pay) instead of reusing what an earlier frame of the same shape on this handle learnt */
+    RT_RENDER_KEEP_TREE = 256u  /* do not regroup the inner nodes of the library's copy of the tree by the rays of this frame
+                                   (see rt_profile.tree_tests_sampled; same image either way; for tests and comparisons) */
 };
 
 typedef struct rt_scene rt_scene; /* opaque */
@@ -331,6 +333,11 @@ typedef struct rt_profile {
     uint64_t segments;                 /* path segments traced (ray queries) */
     uint64_t traverse_segments;        /* segments handled by the stand-alone traverse kernel */
     uint64_t passes;
+    /* The first sizeable pass rendered on a scene handle lends a few hundred of its rays to the library, which regroups the
+     * inner nodes of its copy of the tree so that those rays meet fewer boxes (leaves, their order and so every hit stay as
+     * they are: inner nodes only cull).  These two say what that did, per sampled ray, since the handle was made: box tests
+     * with the tree grouped by box areas and with the tree in use now (equal, or both 0, while nothing has been regrouped). */
+    double tree_tests_by_area, tree_tests_sampled;
 } rt_profile;
 rt_status rt_get_profile(rt_scene* scene, rt_profile* out);
 

@@ -13,6 +13,7 @@ HOST_LIB_PATH = os.path.join(_CSRC, "libraytracing_host.so")
 RT_OK = 0
 RT_ERR_INVALID_ARGUMENT, RT_ERR_EMPTY_SCENE, RT_ERR_UNSUPPORTED, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_OUT_OF_MEMORY = 1, 2, 3, 4, 5, 6
 RT_RENDER_PROFILE, RT_RENDER_NO_TAIL, RT_RENDER_TAIL_ONLY, RT_RENDER_NODES_IN_GLOBAL, RT_RENDER_ONE_STREAM, RT_RENDER_RECALIBRATE, RT_RENDER_ONE_KERNEL, RT_RENDER_TWO_KERNELS = 1, 2, 4, 8, 16, 32, 64, 128
+RT_RENDER_KEEP_TREE = 256
 RT_GEOM_SPHERE, RT_GEOM_MOVING_SPHERE, RT_GEOM_RECT, RT_GEOM_BOX = 0, 1, 2, 3
 RT_PRIM_FLIP, RT_PRIM_MEDIUM, RT_PRIM_INERT, RT_PRIM_BOTH_ROOTS = 1, 2, 4, 8
 RT_MATF_FACE_NORMAL = 1
@@ -98,7 +99,7 @@ class rt_scatter(C.Structure):
 
 class rt_profile(C.Structure):
     _fields_ = [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("samples", C.c_uint64), ("segments", C.c_uint64),
-                ("traverse_segments", C.c_uint64), ("passes", C.c_uint64)]
+                ("traverse_segments", C.c_uint64), ("passes", C.c_uint64), ("tree_tests_by_area", C.c_double), ("tree_tests_sampled", C.c_double)]
 
 
 class camera_options(C.Structure):

@@ -439,7 +439,8 @@ class Scene:
     def profile(self) -> dict:
         p = _abi.rt_profile()
         _abi.check(self._hip.rt_get_profile(self.device(), C.byref(p)))
-        out = {"samples": p.samples, "segments": p.segments, "traverse_segments": p.traverse_segments, "passes": p.passes}
+        out = {"samples": p.samples, "segments": p.segments, "traverse_segments": p.traverse_segments, "passes": p.passes,
+               "tree_tests_by_area": p.tree_tests_by_area, "tree_tests_sampled": p.tree_tests_sampled}
         for k, name in enumerate(_abi.RT_K_NAMES):
             out[name + "_ms"] = p.kernel_ms[k]
             out[name + "_launches"] = p.kernel_launches[k]

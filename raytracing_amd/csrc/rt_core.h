@@ -628,7 +628,26 @@ RT_HD const WalkNode& node_at(const WalkNode* base, uint32_t offset) {  // (the 
 // Inner boxes only cull, so hits do not change.  final_scene: 55.2 box tests per segment with the caller's tree
 // (median splits on random axes, lib.rs:160-200), 41.6 after merely dropping its poor inner nodes, fewer with this.
 struct RegroupNode { float mn[3], mx[3]; uint32_t prim; std::vector<uint32_t> kids; };  // prim == RT_BVH_NONE: inner
-inline void regroup_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_node>& out) {
+// Optionally the expected number of tests is measured instead of modelled: with a sample of the rays a frame really traces
+// (`SampleRays`, taken by the renderer from its queues), the share of rays that meet a box replaces the box's area, counted
+// among the rays that meet the node being regrouped (its runs lie inside its box).  Rays of a path tracer start on the
+// scene's surfaces and mostly end nearby, which areas -- the measure of lines through the whole scene -- know nothing about:
+// final_scene needs 27.2 box tests per segment with 300 sample rays where areas give 34.0 (same leaves, same hits).
+struct SampleRays {
+    std::vector<float> o, inv;  // three floats per ray: origin, 1 / direction
+    size_t size() const { return o.size() / 3; }
+    void add(const float* origin, const float* direction) { for (int c = 0; c < 3; ++c) { o.push_back(origin[c]); inv.push_back(1.0f / direction[c]); } }
+};
+inline bool sample_ray_meets(const SampleRays& R, size_t k, const float* mn, const float* mx) {
+    const float* o = &R.o[3 * k]; const float* iv = &R.inv[3 * k];
+    float tn = 0.001f, tf = INFINITY;
+    for (int c = 0; c < 3; ++c) {
+        const float t0 = (mn[c] - o[c]) * iv[c], t1 = (mx[c] - o[c]) * iv[c];
+        tn = std::fmax(tn, std::fmin(t0, t1)); tf = std::fmin(tf, std::fmax(t0, t1));
+    }
+    return tn <= tf;
+}
+inline void regroup_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_node>& out, const SampleRays* rays = nullptr) {
     out.clear();
     if (n == 0) return;
     const size_t CAP = 32;  // atoms per dynamic programme (its cost grows with the fourth power; 32 measured as good as 64)
@@ -636,6 +655,18 @@ inline void regroup_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_
         const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
         const double a = 2.0 * (dx * dy + dy * dz + dz * dx);
         return (a == a && a > 0.0 && a < 1e300) ? a : 0.0;
+    };
+    // The measure of a box inside the node being regrouped: its area, or (with sample rays) the number of the node's rays
+    // that meet it plus a little of its area, which keeps boxes no sample ray meets in proportion.
+    const size_t n_rays = rays ? rays->size() : 0;
+    const double root_area = n ? area6(in[0].min, in[0].max) : 0.0;
+    const double prior = (n_rays && root_area > 0.0) ? 0.05 * (double)n_rays / root_area : 0.0;
+    std::vector<uint32_t> cand;  // the sample rays that meet the node being regrouped
+    auto measure = [&](const float* mn, const float* mx) {
+        if (!n_rays) return area6(mn, mx);
+        size_t hits = 0;
+        for (uint32_t k : cand) hits += sample_ray_meets(*rays, k, mn, mx);
+        return (double)hits + prior * area6(mn, mx);
     };
     double max_abs = 0.0;
     for (uint32_t i = 0; i < n; ++i)
@@ -657,7 +688,11 @@ inline void regroup_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_
         for (int c = 0; c < 3; ++c) { R.mn[c] = in[i].min[c]; R.mx[c] = in[i].max[c]; }
         R.prim = in[i].prim;
         if (in[i].prim != RT_BVH_NONE) { new_of[i] = (uint32_t)T.size(); T.push_back(R); continue; }
-        const double Ai = area6(in[i].min, in[i].max);
+        if (n_rays) {
+            cand.clear();
+            for (size_t k = 0; k < n_rays; ++k) if (sample_ray_meets(*rays, k, in[i].min, in[i].max)) cand.push_back((uint32_t)k);
+        }
+        const double Ai = measure(in[i].min, in[i].max);
         std::vector<uint32_t>& at = atoms[i];
         for (uint32_t c = i + 1; c < in[i].skip && c < n; c = in[c].skip) {
             if (in[c].prim == RT_BVH_NONE && at.size() + atoms[c].size() <= CAP)  // an inner child is opened up while there is room
@@ -674,7 +709,7 @@ inline void regroup_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_
             float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (int b = a; b < k; ++b) {
                 for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], in[at[b]].min[c]); mx[c] = std::fmax(mx[c], in[at[b]].max[c]); }
-                U[(size_t)a * (k + 1) + b + 1] = area6(mn, mx);
+                U[(size_t)a * (k + 1) + b + 1] = measure(mn, mx);
                 float* ub = &ubox[((size_t)a * (k + 1) + b + 1) * 6];
                 for (int c = 0; c < 3; ++c) { ub[c] = mn[c]; ub[3 + c] = mx[c]; }
             }
@@ -685,7 +720,7 @@ inline void regroup_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_
         std::vector<double> s_of((size_t)k * (k + 1), 0.0);
         std::vector<std::vector<int>> pred((size_t)k * (k + 1));
         auto S = [&](int a, int b) -> double& { return s_of[(size_t)a * (k + 1) + b]; };
-        for (int a = 0; a < k; ++a) S(a, a + 1) = area6(in[at[a]].min, in[at[a]].max) * cost[at[a]];
+        for (int a = 0; a < k; ++a) S(a, a + 1) = measure(in[at[a]].min, in[at[a]].max) * cost[at[a]];
         auto partition = [&](int a, int b, double parent_area, bool need_two, std::vector<int>& pr) {
             const int m = b - a;
             std::vector<double> G(m + 1, INFINITY);
@@ -756,9 +791,9 @@ inline void regroup_nodes(const rt_bvh_node* in, uint32_t n, std::vector<rt_bvh_
 
 // (host side) The walk's node array for a scene description: inner nodes regrouped, payload slots inserted, skip links
 // remapped, leaves annotated, sentinel appended.  nodes.size() - 1 is the SceneView's n_bvh_nodes.
-inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes) {
+inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes, const SampleRays* rays = nullptr) {
     std::vector<rt_bvh_node> tree;
-    regroup_nodes(D->bvh, D->n_bvh_nodes, tree);
+    regroup_nodes(D->bvh, D->n_bvh_nodes, tree, rays);
     const uint32_t n_in = (uint32_t)tree.size();
     std::vector<uint32_t> new_index(n_in + 1);
     auto plain_sphere = [&](const rt_bvh_node& N) {

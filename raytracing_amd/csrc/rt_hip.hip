@@ -103,6 +103,23 @@ __global__ void __launch_bounds__(RT_BS) k_raygen(PassParams P, RayQueue q, uint
     q.thr[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
 }
 
+// A few rays of a queue, evenly spaced over it, for the host (see tune_tree): out[k] = {origin, direction} of entry
+// (k + 1/2) * count / n; a zero direction where the queue is empty.
+#define RT_TUNE_BOUNCES 16u      // bounces of the sampled pass that lend rays
+#define RT_TUNE_PER_BOUNCE 20u   // rays per bounce
+#define RT_TUNE_MIN_PATHS (1u << 18)  // a pass lends rays if it holds at least this many paths
+__global__ void __launch_bounds__(64) k_sample_rays(RayQueue q, const uint32_t* count_ptr, uint32_t n_counts, uint32_t capacity, uint32_t n, float* out) {
+    const uint32_t k = threadIdx.x;
+    if (k >= n) return;
+    const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[n_counts];
+    float* o = out + 6u * k;
+    if (count == 0) { for (int c = 0; c < 6; ++c) o[c] = 0.0f; return; }
+    const uint32_t i = (uint32_t)(((uint64_t)(2u * k + 1u) * count) / (2u * n));
+    const uint32_t at = queue_slot(i < count ? i : count - 1u, n_front, capacity);
+    const float4 a = q.od0[at], b = q.od1[at];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y;
+}
+
 // The pixels this rank owns, tile by tile (tile_id = ty * ntx + tx, owner = tile_id % world_size), rows of a tile bottom-up
 // and left to right: owned[k] = j * width + i.  One workgroup: every thread takes a tile, a scan over the tiles' pixel
 // counts gives each its place in the list.  (The order of the list only lays out the workspace; every draw is keyed by
@@ -204,10 +221,10 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 #endif
 #define RT_TRAV_GROUP 256u    // rays dealt to a workgroup at a time
 #ifndef RT_STUCK_MAX
-#define RT_STUCK_MAX 12       // ... or once this many lanes cannot step (two leaves pending, or out of the tree with one)
+#define RT_STUCK_MAX 20       // ... or once this many lanes cannot step (two leaves pending, or out of the tree with one)
 #endif
 #ifndef RT_STEPS_PER_TURN
-#define RT_STEPS_PER_TURN 12  // node steps between two looks at the wave's state
+#define RT_STEPS_PER_TURN 10  // node steps between two looks at the wave's state
 #endif
 #ifdef RT_TRAV_STATS
 // Analysis build only: what the waves of k_traverse spend their turns on (summed over all launches since the last read).
@@ -636,6 +653,12 @@ struct rt_scene {
     uint32_t* h_counts = nullptr;  // pinned
     std::vector<void*> ws_allocs;
     std::vector<Calibration> calibrations;
+    // what make_walk_nodes reads of the caller's description, kept for regrouping the tree by sampled rays (tune_tree)
+    struct HostTree { std::vector<rt_prim> prims; std::vector<rt_sphere> spheres; std::vector<rt_rect> rects; std::vector<rt_box> boxes;
+                      std::vector<rt_xform> xforms; std::vector<rt_bvh_node> bvh; rt_scene_desc d{}; } host;
+    bool tree_tuned = false;
+    double tree_tests_by_area = 0.0, tree_tests_sampled = 0.0;
+    float* d_tune_rays = nullptr;  // RT_TUNE_BOUNCES x RT_TUNE_PER_BOUNCE x 6 floats
     // profile
     rt_profile prof{};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> events;
@@ -833,6 +856,23 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     UP(images, D->images, D->n_images);
     UP(texels, D->texels, D->texel_bytes);
     UP(perm, D->perm_tables, 256u * (size_t)D->n_perm_tables);
+    {   // what a later regrouping of the tree needs of the description (the caller's arrays are only valid during this call)
+        rt_scene::HostTree& H = sc->host;
+        H.prims.assign(D->prims, D->prims + D->n_prims);
+        if (D->n_spheres) H.spheres.assign(D->spheres, D->spheres + D->n_spheres);
+        if (D->n_rects) H.rects.assign(D->rects, D->rects + D->n_rects);
+        if (D->n_boxes) H.boxes.assign(D->boxes, D->boxes + D->n_boxes);
+        if (D->n_xforms) H.xforms.assign(D->xforms, D->xforms + D->n_xforms);
+        if (D->n_bvh_nodes) H.bvh.assign(D->bvh, D->bvh + D->n_bvh_nodes);
+        H.d = rt_scene_desc{};
+        H.d.n_prims = D->n_prims; H.d.n_spheres = D->n_spheres; H.d.n_rects = D->n_rects; H.d.n_boxes = D->n_boxes; H.d.n_xforms = D->n_xforms;
+        H.d.n_bvh_nodes = D->n_bvh_nodes;
+        H.d.prims = H.prims.data(); H.d.spheres = H.spheres.data(); H.d.rects = H.rects.data(); H.d.boxes = H.boxes.data(); H.d.xforms = H.xforms.data();
+        H.d.bvh = H.bvh.data();
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)RT_TUNE_BOUNCES * RT_TUNE_PER_BOUNCE * 6 * sizeof(float)) != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc failed"); }
+        sc->allocs.push_back(p); sc->d_tune_rays = static_cast<float*>(p);
+    }
     {   // the walk's own node array (payload slots, leaf annotations, sentinel)
         std::vector<WalkNode> nodes;
         make_walk_nodes(D, nodes);
@@ -993,6 +1033,58 @@ static uint64_t count_owned(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, ui
 // Renders this rank's pixels into d_mean_out (full frame of doubles on the device).
 // `fixed`: the workspace of the variant that allocates nothing (null: the scene handle's own, grown as needed).  That
 // variant also creates no events and reads nothing back: it hands over to k_tail at a bounce fixed in advance.
+// Box tests a ray makes on its way through a node array when nothing it meets stops it (no primitive tests: every leaf it
+// reaches counts as passed): what regrouping the inner nodes changes, for the statistics of rt_profile.
+static double node_tests_per_ray(const std::vector<WalkNode>& nodes, const SampleRays& rays) {
+    if (nodes.size() < 2 || rays.size() == 0) return 0.0;
+    const uint32_t end = (uint32_t)(nodes.size() - 1) * RT_NODE_STRIDE;
+    uint64_t tests = 0;
+    for (size_t k = 0; k < rays.size(); ++k) {
+        const V3 inv = walk_cap(v3(rays.inv[3 * k], rays.inv[3 * k + 1], rays.inv[3 * k + 2]));
+        const V3 oi = v3(rays.o[3 * k] * inv.x, rays.o[3 * k + 1] * inv.y, rays.o[3 * k + 2] * inv.z);
+        for (uint32_t i = 0; i < end;) {
+            const WalkNode& N = node_at(nodes.data(), i);
+            ++tests;
+            i = (node_hit(N, inv, oi, 0.001f, RT_WALK_FAR) && N.prim < RT_NODE_LEAF) ? N.prim : N.skip;
+        }
+    }
+    return (double)tests / (double)rays.size();
+}
+
+// Regroups the inner nodes of the library's copy of the tree by a sample of the rays a pass has traced (d_tune_rays, filled
+// by k_sample_rays; the stream is idle).  Leaves, their order and their boxes stay, so no hit and no image changes; the walk
+// meets fewer boxes (final_scene: 27 instead of 34 a segment).  Done once per scene handle.  Failure to improve, or a node
+// array that no longer fits where the old one did, leaves everything as it was.
+static rt_status tune_tree(rt_scene* sc, uint32_t n_bounces) {
+    std::vector<float> h((size_t)n_bounces * RT_TUNE_PER_BOUNCE * 6);
+    HIP_TRY(hipMemcpy(h.data(), sc->d_tune_rays, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    SampleRays rays;
+    for (size_t k = 0; k < h.size() / 6; ++k) {
+        const float* r = &h[6 * k];
+        bool ok = true;
+        for (int c = 0; c < 6; ++c) ok = ok && r[c] - r[c] == 0.0f;
+        if (ok && (r[3] != 0.0f || r[4] != 0.0f || r[5] != 0.0f)) rays.add(r, r + 3);
+    }
+    if (rays.size() < 64) return RT_OK;  // (too few: a later, larger pass may lend more)
+    sc->tree_tuned = true;
+    std::vector<WalkNode> before, after;
+    make_walk_nodes(&sc->host.d, before);
+    make_walk_nodes(&sc->host.d, after, &rays);
+    const double t_before = node_tests_per_ray(before, rays), t_after = node_tests_per_ray(after, rays);
+    sc->tree_tests_by_area = t_before; sc->tree_tests_sampled = t_before;
+    const size_t bytes = after.size() * sizeof(WalkNode);
+    const bool fits = !sc->nodes_fit_lds || bytes + RT_LDS_BEHIND_NODES + sc->view.lds_scene_bytes <= RT_LDS_NODE_LIMIT;
+    if (!(t_after < t_before) || !fits || bytes >= RT_NODE_LEAF) return RT_OK;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return RT_OK; }
+    sc->allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, after.data(), bytes, hipMemcpyHostToDevice));
+    sc->view.bvh = static_cast<const WalkNode*>(p);  // (the old array stays allocated until the handle goes: nothing reads it any more)
+    sc->view.n_bvh_nodes = (uint32_t)after.size() - 1;
+    sc->tree_tests_sampled = t_after;
+    return RT_OK;
+}
+
 static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out, bool sync_at_end,
                              const Workspace* fixed) {
     rt_status st = validate_render(sc, cam, io, ro);
@@ -1060,9 +1152,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     HIP_TRY(hipMemsetAsync(ws.accum, 0, (size_t)n_owned * 3 * sizeof(double), stream));
 
     const uint32_t max_grid = sc->n_cu * 8u;
-    const size_t node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
+    size_t node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
     const bool nodes_in_lds = sc->nodes_fit_lds && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
-    const size_t lds_bytes = node_bytes + RT_LDS_BEHIND_NODES + sc->view.lds_scene_bytes;  // dynamic LDS of the kernels that stage the nodes
+    size_t lds_bytes = node_bytes + RT_LDS_BEHIND_NODES + sc->view.lds_scene_bytes;  // dynamic LDS of the kernels that stage the nodes (changes when the tree is regrouped)
     const uint32_t tail_threshold = sc->n_cu * 512u;
     Launcher L{sc, stream, profile};
     hipEvent_t ev;
@@ -1151,12 +1243,21 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             sc->prof.samples += h.P.n_paths;
         }
         sc->prof.passes += 1;
+        // The first sizeable pass on a scene handle lends some of its rays to the regrouping of the tree (tune_tree).
+        const bool sampling = !fixed && !sc->tree_tuned && !(ro->flags & RT_RENDER_KEEP_TREE) && !fused && sc->n_leaves > RT_SCAN_MAX_LEAVES &&
+                              half[0].P.n_paths >= RT_TUNE_MIN_PATHS;
+        uint32_t sampled_bounces = 0;
         uint32_t b = 0;
         bool finished = false;
         for (; b < depth; ++b) {
             if (tail_from >= 0 && !force_wavefront && (int)b >= tail_from) break;
             for (int k = 0; k < n_halves; ++k) {  // (event timing only in one-half passes: L works on `stream`)
                 Half& h = half[k];
+                if (sampling && k == 0 && b < RT_TUNE_BOUNCES) {
+                    hipLaunchKernelGGL(k_sample_rays, dim3(1), dim3(64), 0, h.stream, h.q[h.cur], h.counts + b, n_counts, h.P.n_paths, RT_TUNE_PER_BOUNCE,
+                                       sc->d_tune_rays + (size_t)b * RT_TUNE_PER_BOUNCE * 6);
+                    sampled_bounces = b + 1;
+                }
                 if (!fused) {
                     if (n_halves == 1 && (st = L.begin(RT_K_TRAVERSE, &ev)) != RT_OK) return st;
                     launch_traverse(h, b, grid[k], trav_grid[k]);
@@ -1221,6 +1322,12 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 if (known) *known = c;
                 else { if (sc->calibrations.size() >= 64) sc->calibrations.erase(sc->calibrations.begin()); sc->calibrations.push_back(c); known = &sc->calibrations.back(); }
             }
+        }
+        if (sampling && sampled_bounces > 0) {
+            HIP_TRY(hipStreamSynchronize(stream));  // (the pass is complete: resolve has waited for every part)
+            if ((st = tune_tree(sc, sampled_bounces)) != RT_OK) return st;
+            node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
+            lds_bytes = node_bytes + RT_LDS_BEHIND_NODES + sc->view.lds_scene_bytes;
         }
     }
     L.profile = profile;
@@ -1297,6 +1404,7 @@ rt_status rt_debug_trav_stats(unsigned long long* out16) {
 rt_status rt_get_profile(rt_scene* sc, rt_profile* out) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     *out = sc->prof;
+    out->tree_tests_by_area = sc->tree_tests_by_area; out->tree_tests_sampled = sc->tree_tests_sampled;  // (of the handle, not of the last call)
     return RT_OK;
 }
 

@@ -585,3 +585,30 @@ def test_final_scene_book_variant_renders(earth):
     d = sc.desc
     media = {i for i in range(d.n_prims) if d.prims[i].flags & _abi.RT_PRIM_MEDIUM}
     assert len(media) == 2 and media & set(int(p) for p in hits["prim"][hits["hit"] == 1])
+
+
+def test_tree_regrouped_by_sampled_rays_keeps_every_byte(earth):
+    """The first sizeable pass on a scene handle lends rays to the library, which regroups the inner nodes of its copy of the
+    tree by them (rt_profile.tree_tests_*): fewer box tests, the same leaves in the same order, so the same hit records and the
+    same frame, bit for bit; RT_RENDER_KEEP_TREE holds it off."""
+    sc, co = _example("final_scene", earth)
+    cam = rt.Camera(co)
+    io = rt.ImageOptions(400, 400, 8, 50)
+    rng = np.random.default_rng(9)
+    rays = sc.camera_rays(cam, io, 1, rng.integers(0, 400, 20000), rng.integers(0, 400, 20000), rng.integers(0, 8, 20000))
+    hits0 = sc.intersect_batch(rays[:, 0:3], rays[:, 3:6], rays[:, 6], seed=3)
+    _, kept = sc.render(cam, io, rt.RenderOptions(seed=4, flags=_abi.RT_RENDER_KEEP_TREE), want_mean=True)
+    p = sc.profile()
+    assert p["tree_tests_by_area"] == 0.0 and p["tree_tests_sampled"] == 0.0
+    _, small = sc.render(cam, rt.ImageOptions(64, 64, 8, 50), rt.RenderOptions(seed=4), want_mean=True)   # too small a pass to lend rays
+    assert sc.profile()["tree_tests_sampled"] == 0.0
+    _, tuned = sc.render(cam, io, rt.RenderOptions(seed=4), want_mean=True)
+    p = sc.profile()
+    assert 0.0 < p["tree_tests_sampled"] < 0.9 * p["tree_tests_by_area"], p
+    assert np.array_equal(kept, tuned)
+    _, after = sc.render(cam, io, rt.RenderOptions(seed=4), want_mean=True)
+    assert np.array_equal(kept, after) and sc.profile()["tree_tests_sampled"] == p["tree_tests_sampled"]          # regrouped once
+    for flags in (_abi.RT_RENDER_NODES_IN_GLOBAL, _abi.RT_RENDER_TAIL_ONLY, _abi.RT_RENDER_ONE_STREAM):
+        assert np.array_equal(sc.render(cam, io, rt.RenderOptions(seed=4, flags=flags), want_mean=True)[1], kept)
+    hits1 = sc.intersect_batch(rays[:, 0:3], rays[:, 3:6], rays[:, 6], seed=3)
+    assert hits0.tobytes() == hits1.tobytes()

@@ -23,6 +23,8 @@ static inline void twin_count_generic_leaves() { g_generic_leaves++; }
 using namespace rt;
 
 namespace {
+// Sample rays for the regrouping of the inner nodes (see SampleRays in rt_core.h); none = areas.
+SampleRays g_sample_rays;
 // The scene as the kernels see it: the caller's arrays plus the walk's own node array.
 struct TwinScene {
     SceneView V{};
@@ -36,7 +38,7 @@ struct TwinScene {
         V.prims = D->prims; V.spheres = D->spheres; V.rects = rects.data(); V.boxes = boxes.data(); V.xforms = D->xforms;
         make_shade_records(D, shade);
         V.shade = shade.data(); V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
-        if (with_nodes) make_walk_nodes(D, nodes);
+        if (with_nodes) make_walk_nodes(D, nodes, g_sample_rays.size() ? &g_sample_rays : nullptr);
         V.bvh = nodes.data();
         V.n_prims = D->n_prims; V.n_bvh_nodes = with_nodes ? (uint32_t)nodes.size() - 1 : 0;
         for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
@@ -94,7 +96,10 @@ void twin_material_scatter(const rt_scene_desc* D, const rt_hit* h, uint64_t see
 }
 
 unsigned long long twin_generic_leaves(void) { return g_generic_leaves; }
-
+void twin_set_sample_rays(const rt_ray* rays, uint64_t n) {
+    g_sample_rays = SampleRays();
+    for (uint64_t i = 0; i < n; ++i) g_sample_rays.add(rays[i].origin, rays[i].direction);
+}
 // Per-ray traversal work (nodes visited, leaves reached, primitive tests run) for analysis.
 // trace (optional, n x trace_cap): the node-visit count at which each leaf was reached.
 void twin_traverse_stats(const rt_scene_desc* D, const rt_ray* rays, uint64_t n, uint64_t seed, uint32_t* out /* n x 3 */, uint32_t* trace, uint32_t trace_cap) {
@@ -158,7 +163,7 @@ void twin_traverse_ordered(const rt_scene_desc* D, const rt_ray* rays, uint64_t 
 // slots including the sentinel and copies up to `cap` of them (8 x uint32 per slot) to `out`.
 uint32_t twin_walk_nodes(const rt_scene_desc* D, uint32_t* out, uint32_t cap) {
     std::vector<WalkNode> nodes;
-    make_walk_nodes(D, nodes);
+    make_walk_nodes(D, nodes, g_sample_rays.size() ? &g_sample_rays : nullptr);
     const size_t n = std::min<size_t>(nodes.size(), cap);
     if (out && n) std::memcpy(out, nodes.data(), n * sizeof(WalkNode));
     return (uint32_t)nodes.size();

@@ -16,7 +16,8 @@ for flags in flags_list:
     _ = sc.render(cam, io, rt.RenderOptions(seed=1, flags=flags | 1)); p = sc.profile()
     if ref is None: ref = mean
     print('flags', flags, 'spp', spp, '%.3fs' % (t1 - t0), 'Msamples/s %.1f' % (800 * 800 * spp / (t1 - t0) / 1e6), 'identical to first:', np.array_equal(ref, mean, equal_nan=True), 'nan px', int(np.isnan(mean).any(axis=2).sum()),
-          {k: round(v, 1) for k, v in p.items() if k.endswith('_ms')}, 'trav launches', p['traverse_launches'], flush=True)
+          {k: round(v, 1) for k, v in p.items() if k.endswith('_ms')}, 'trav launches', p['traverse_launches'],
+          'box tests per sampled ray %.1f -> %.1f' % (p['tree_tests_by_area'], p['tree_tests_sampled']), flush=True)
 for name, w, h, s in [('cornell', 600, 600, 256), ('perlin', 1920, 1080, 64), ('cornell_smoke', 800, 800, 128), ('random_spheres', 400, 225, 256)]:
     sc2, co2 = rt.Scene.example(name, 1); cam2 = rt.Camera(co2)
     io2 = rt.ImageOptions(h, w, s, 50)

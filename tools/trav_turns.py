@@ -8,8 +8,11 @@ from raytracing_amd import _abi
 lib = C.CDLL(_abi.HIP_LIB_PATH)
 sc, co = rt.Scene.example('final_scene', 1, rt.earthmap()); cam = rt.Camera(co)
 out = (C.c_ulonglong * 16)()
+keep = 256 if len(sys.argv) > 1 and sys.argv[1] == 'keep-tree' else 0   # RT_RENDER_KEEP_TREE: the tree grouped by box areas
+sc.render(cam, rt.ImageOptions(800, 800, 16, 50), rt.RenderOptions(seed=1, flags=keep))   # (lends rays: the tree is regrouped before the counted frame)
+print('box tests per sampled ray: %.1f by areas, %.1f in use' % (sc.profile()['tree_tests_by_area'], sc.profile()['tree_tests_sampled']))
 lib.rt_debug_trav_stats(out)
-sc.render(cam, rt.ImageOptions(800, 800, 16, 50), rt.RenderOptions(seed=1, flags=1 | 2 | 16))
+sc.render(cam, rt.ImageOptions(800, 800, 16, 50), rt.RenderOptions(seed=1, flags=1 | 2 | 16 | keep))
 seg = sc.profile()['segments']
 assert lib.rt_debug_trav_stats(out) == 0
 s = list(out)
