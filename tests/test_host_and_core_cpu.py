@@ -582,3 +582,49 @@ def test_final_scene_book_variant_flattens_with_the_switches(earth):
     assert sum(1 for i in range(da.n_prims) if da.prims[i].flags & _abi.RT_PRIM_INERT) == 2
     leaves = lambda d: sum(1 for k in range(d.n_bvh_nodes) if d.bvh[k].prim != _abi.RT_BVH_NONE)
     assert leaves(db) == 1410 and leaves(da) == 1408
+
+
+def test_regrouping_by_sample_rays_keeps_leaves_and_hits(earth):
+    """The inner nodes of the walk's tree regrouped by the share of sample rays that meet a box instead of by box areas
+    (SampleRays in rt_core.h; the renderer samples its own queues): the same leaves in the same order with the same payloads,
+    hit records equal bit for bit, a fifth fewer box tests on the rays of final_scene."""
+    from oracle_lib import rays_to_c
+    tw = twin()
+    sc, co = _example("final_scene", earth)
+    osc, oco = OracleScene.example("final_scene", 1, earth)
+    desc = sc._host.rth_scene_desc(sc._h)
+    LEAF = 0x10000000
+
+    def rays_of(seed, n):
+        parts = list(path_rays(osc, oco, 64, 64, 5, n, 8, np.random.default_rng(seed)))
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
+
+    def leaves_and_payloads(raw):
+        out, i, n = [], 0, len(raw) - 1
+        while i < n:
+            if raw[i, 7] >= LEAF:
+                nxt = raw[i, 6] // 32
+                out.append((int(raw[i, 7]), raw[i + 1:nxt].tobytes()))
+                i = nxt
+            else:
+                i += 1
+        return out
+
+    def work(o, d, t):
+        rays = rays_to_c(o, d, t)
+        out = np.zeros((len(rays), 3), dtype=np.uint32)
+        tw.twin_traverse_stats(desc, rays.ctypes.data, len(rays), 1, out.ctypes.data, None, 0)
+        return out.sum(axis=0) / len(rays)
+
+    test = rays_of(3, 1200)
+    train = rays_to_c(*(a[:300] for a in rays_of(11, 60)))
+    raw0, hits0, work0 = _walk_nodes(sc), twin_intersect(sc, *test), work(*test)
+    tw.twin_set_sample_rays(train.ctypes.data, len(train))
+    try:
+        raw1, hits1, work1 = _walk_nodes(sc), twin_intersect(sc, *test), work(*test)
+    finally:
+        tw.twin_set_sample_rays(None, 0)
+    assert leaves_and_payloads(raw0) == leaves_and_payloads(raw1) and len(leaves_and_payloads(raw0)) == 1408
+    assert hits0.tobytes() == hits1.tobytes()
+    assert work1[0] < 0.85 * work0[0] and work1[1] == work0[1] and work1[2] == work0[2], (work0, work1)   # box tests; leaves reached and primitive tests as before
+    assert np.array_equal(_walk_nodes(sc), raw0)                                                         # without sample rays: by areas again
