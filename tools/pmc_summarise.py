@@ -2,7 +2,9 @@
 
     python tools/pmc_summarise.py gpurun_out/pmc profiles/r02_pmc.json profiles/r02_pmc_summary.md
 
-Per configuration and kernel (k_traverse, k_shade), summed over all launches of the run:
+The workload renders a first frame of one sample per pixel (after which the library regroups the tree by sampled rays) and
+then the measured frame; launches dispatched before the end of the first frame (its k_finalize) are left out.
+Per configuration and kernel (k_traverse, k_shade), summed over the launches of the measured frame:
   valu_busy        SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)   share of cycles a SIMD issues a vector instruction
   l2_hit_rate      TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
   hbm_bytes        (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB, and on gfx950 FETCH_SIZE tallies the 128-byte
@@ -26,15 +28,23 @@ def kernel_of(name):
     return None
 
 
+def measured_rows(f):
+    """The rows of a rocprofv3 csv whose dispatch comes after the first k_finalize launch (all rows if there is only one frame)."""
+    with open(f) as fh:
+        rows = list(csv.DictReader(fh))
+    ends = sorted({int(r["Dispatch_Id"]) for r in rows if "k_finalize" in r["Kernel_Name"]})
+    cut = ends[0] if len(ends) > 1 else -1
+    return [r for r in rows if int(r["Dispatch_Id"]) > cut]
+
+
 def read_counters(d):
     """{kernel: {counter: sum}} of a --pmc run's counter_collection csv."""
     out = defaultdict(lambda: defaultdict(float))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                k = kernel_of(row["Kernel_Name"])
-                if k:
-                    out[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        for row in measured_rows(f):
+            k = kernel_of(row["Kernel_Name"])
+            if k:
+                out[k][row["Counter_Name"]] += float(row["Counter_Value"])
     return out
 
 
@@ -42,18 +52,18 @@ def read_durations(d):
     """{kernel: (launches, total ns)} of the trace run's kernel_trace csv."""
     out = defaultdict(lambda: [0, 0.0])
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-        with open(f) as fh:
-            for row in csv.DictReader(fh):
-                k = kernel_of(row["Kernel_Name"])
-                if k:
-                    out[k][0] += 1
-                    out[k][1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        for row in measured_rows(f):
+            k = kernel_of(row["Kernel_Name"])
+            if k:
+                out[k][0] += 1
+                out[k][1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
     return out
 
 
 def main(root, out_json, out_md):
     doc = {"source": "rocprofv3 --pmc, one run per counter group (SQ_*, TCC_HIT/MISS, FETCH_SIZE, WRITE_SIZE) plus a --kernel-trace run, on "
-                     "tools/prof_workload.py <config> <spp> (RT_RENDER_NO_TAIL | RT_RENDER_ONE_STREAM: one k_traverse and one k_shade launch per bounce)",
+                     "tools/prof_workload.py <config> <spp> (RT_RENDER_NO_TAIL | RT_RENDER_ONE_STREAM: one k_traverse and one k_shade launch per bounce; "
+                     "the launches of its first frame of 1 spp, after which the tree is regrouped by sampled rays, are left out)",
            "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB counters; gfx950 FETCH_SIZE counts half of wide coalesced reads)",
            "configs": {}}
     lines = ["| config | kernel | launches | ms total | VALU busy | VALU lane slots / segment | L2 hit rate | HBM B / segment (algorithmic) | HBM GB/s | wait share |",
