@@ -204,24 +204,21 @@ RT_HD D3 sphere_center(const rt_sphere& sp, bool moving, float time) {
     }
     return c;
 }
-// Square root and reciprocal in f64 for the sphere's root.  On the GPU: the hardware estimate refined to within an ulp
-// or two (a quarter of the instructions of the correctly rounded library routines; the root is rounded to fp32
-// afterwards).  On the host: the plain operations.
+// Square root and reciprocal in f64 for the sphere's root.  On the GPU: the hardware estimate (good to 2^-23) refined to
+// within an ulp or two for the square root and to 2^-46 for the reciprocal, a fifth of the instructions of the correctly
+// rounded library routines; the root is rounded to fp32 afterwards, 2^22 times coarser.  On the host: the plain operations.
 #if defined(__HIP_DEVICE_COMPILE__)
 RT_HD double sqrt_near(double x) {
     const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
+    double g = x * y, h = 0.5 * y;  // (one coupled step squares the estimate's 2^-23, the correction squares that again)
+    const double r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
     g = fma(fma(-g, g, x), h, g);
     return x == 0.0 ? 0.0 : g;
 }
 RT_HD double rcp_near(double x) {
     double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);  // (one step: 2^-46 from an estimate good to 2^-23)
     return r;
 }
 RT_HD double rsqrt_near(double x) {  // 1 / sqrt(x) for positive finite x
@@ -376,7 +373,7 @@ RT_HD bool box_t<float, V3>(const DevBox& B, V3 o, V3 d, float tmin, float tmax,
 }
 
 // The f64 form (boxes behind Translated / Rotated wrappers, boundaries of media): the same six sides with the plane parameters
-// formed as (bound - origin) * (1 / direction), the three reciprocals refined to within an ulp or two (rcp_near).  The
+// formed as (bound - origin) * (1 / direction), the three reciprocals refined to within an ulp or two (rcp_exact_at_zero).  The
 // reference divides (shape.rs:321); the product differs from the quotient by a couple of f64 ulps, nine orders of magnitude
 // below the fp32 rounding of the accepted t, and goes to +-inf / NaN for a zero direction component exactly as the quotient
 // does.  Six f64 divisions were two thirds of the instructions of this test.

@@ -230,7 +230,8 @@ __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds)
 // Analysis build only: what the waves of k_traverse spend their turns on (summed over all launches since the last read).
 // 0 step turns, 1 lanes that could step at the start of a step turn, 2 leaf turns, 3 lanes with a leaf pending at a leaf turn,
 // 4 / 5 / 6 lanes whose oldest leaf is a sphere / a box / something else at a leaf turn, 7 leaf turns that hold more than one kind,
-// 8 refills, 9 rays taken, 10 / 11 leaves tried in the first / second round of the leaf turns
+// 8 refills, 9 rays taken, 10 / 11 leaves tried in the first / second round of the leaf turns, 12 / 13 leaf turns with a plain
+// rectangle in the second round and the lanes that hold one, 14 / 15 the same for leaves that are neither sphere, box nor rectangle
 __device__ unsigned long long g_trav_stats[16];
 #define RT_STAT(k, v) do { if (lane == 0) st[k] += (v); } while (0)
 #else
@@ -333,6 +334,12 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
                 const uint32_t leaf = has ? node_at(S.bvh, p0).prim : 0u;
 #ifdef RT_TRAV_STATS
                 { const uint32_t served = (uint32_t)__popcll(__ballot(has && ((leaf & RT_NODE_PLAIN_SPHERE) != 0u) == (round == 0))); RT_STAT(10 + round, served); }
+                if (round == 1) {
+                    const bool mine = has && (leaf & RT_NODE_PLAIN_SPHERE) == 0u;
+                    const uint32_t n_rect = (uint32_t)__popcll(__ballot(mine && (leaf & RT_NODE_PLAIN_RECT) != 0u));
+                    const uint32_t n_other = (uint32_t)__popcll(__ballot(mine && (leaf & (RT_NODE_PLAIN_RECT | RT_NODE_PLAIN_BOX)) == 0u));
+                    RT_STAT(12, n_rect != 0 ? 1 : 0); RT_STAT(13, n_rect); RT_STAT(14, n_other != 0 ? 1 : 0); RT_STAT(15, n_other);
+                }
 #endif
                 if (has && ((leaf & RT_NODE_PLAIN_SPHERE) != 0u) == (round == 0)) {
                     Walk w; walk_init(w, t_end);

@@ -8,7 +8,7 @@ cp $lib /tmp/librt_hip.keep.so
 rc=0
 for v in raytracing_amd/csrc/variants/*.so; do
     cp "$v" $lib
-    line=$(timeout -k 10 200 python tools/gpu_perf.py ${1:-1024} 0 2>&1 | grep -m1 flags) || { rc=1; echo "$(basename $v) failed"; break; }
+    line=$(timeout -k 10 200 python tools/gpu_perf.py ${1:-1024} ${2:-0} 2>&1 | grep -m1 flags) || { rc=1; echo "$(basename $v) failed"; break; }
     echo "$(basename $v .so) $line"
 done
 cp /tmp/librt_hip.keep.so $lib
