@@ -1317,12 +1317,13 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         if ((st = L.end(ev)) != RT_OK) return st;
         if (calibrating) {
             // Two halves on two streams pay when the instruction-bound traversal dominates the memory-bound shading (they
-            // then fill each other's gaps); with small trees both kernels wait on the same queue traffic and splitting
-            // only halves the work per launch.
+            // then fill each other's gaps), and when a bounce is one kernel (the last workgroups of one half's launch run
+            // beside the first of the other's: 5 % on the Cornell rooms, three or four parts are slower again).  Two-kernel
+            // bounces of small trees keep one stream: both kernels wait on the same queue traffic.
             HIP_TRY(hipStreamSynchronize(stream));
             const rt_profile keep = sc->prof;
             if ((st = collect_profile(sc)) != RT_OK) return st;
-            split_pays = sc->prof.kernel_ms[RT_K_TRAVERSE] - keep.kernel_ms[RT_K_TRAVERSE] > 1.5 * (sc->prof.kernel_ms[RT_K_SHADE] - keep.kernel_ms[RT_K_SHADE]);
+            split_pays = fused || sc->prof.kernel_ms[RT_K_TRAVERSE] - keep.kernel_ms[RT_K_TRAVERSE] > 1.5 * (sc->prof.kernel_ms[RT_K_SHADE] - keep.kernel_ms[RT_K_SHADE]);
             sc->prof = keep;
             if (!force_wavefront && !force_tail && ns == S) {  // (a full-size pass: what it saw holds for the passes to come)
                 const Calibration c{W, H, depth, n_owned, tail_from, split_pays};
