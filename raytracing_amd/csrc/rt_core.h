@@ -506,7 +506,11 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
             flip_side = !upper;  // the x0 / y0 / z0 sides are Flipped (outward normals)
         }
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
-        const double t64 = (hgt - compd(o, oo)) / compd(d, oo);  // shape.rs:321 (a true division: a ray parallel to the plane must give +-inf or NaN as there)
+        // shape.rs:321.  A true division: a ray parallel to the plane must give +-inf or NaN as there, and the point's coordinate
+        // on the plane's axis, origin + quotient * direction, must cancel to exactly the plane's as often as the reference's does
+        // (a product with a refined reciprocal is two ulps off and cancels half as often, which shifts cornell_smoke's frame
+        // mean by two of its standard errors: the smoke boxes stand on the floor's plane)
+        const double t64 = (hgt - compd(o, oo)) / compd(d, oo);
         const D3 p = ray_at(o, d, t64);
         if (want_uv) {
             double x0, y0, x1, y1, h_, unused;
