@@ -453,6 +453,7 @@ struct Hit {  // IntersectionPoint (shape.rs:539-550)
     float t, u, v;
     V3 point, normal, in_vec;
     uint32_t prim;
+    V3 point_err = v3(0.0f, 0.0f, 0.0f);  // the f64 point minus `point`, for the surfaces where shade_step needs it (see side_of_surface); zero elsewhere
 };
 
 // Point, normal and surface coordinates in the shape's frame for an accepted (t, side).  Runs once per
@@ -531,6 +532,39 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
     pt_out = d3(px, py, pz); n_out = d3(nx, ny, nz); u = uu; v = vv;
 }
 
+// A ray's origin is kept in fp32.  The reference's f64 hit point lies on its plane to an ulp of f64, so a ray that leaves
+// a surface never meets that surface again: the quotient (plane - origin) / direction is far below tmin = 0.001.  Rounded to
+// fp32 the point of a plane that is not aligned with the axes (a box or rectangle behind Rotated / Translated) lies up to
+// 2e-5 off it, half of the time behind it, and directions are not normalised (normal + unit vector: a length of 0.05 is
+// common), so 0.001 in the ray's parameter can be less than that: 0.3 % of the rays leaving Cornell's tall box met the face
+// they started on, mostly rays along the face, among them the ones that go straight up to the light: the box's sides came
+// out 3 % darker and the frame 0.34 % (tools/bias_check.py; rounding the origins of the f64 oracle to fp32 shows the same).
+// For those surfaces the origin is therefore rounded to the side of the plane the new ray leaves on: a component whose
+// fp32 value fell short of the f64 point in that direction moves one fp32 step along it.  Axis-aligned planes at fp32
+// coordinates (every wall, every plain box side) are exact and untouched, spheres never meet a ray from within (near root
+// only), and a medium has no surface.
+RT_HD bool plane_off_grid(const rt_prim& P) {
+    return P.xf_count > 0 && (P.geom == RT_GEOM_BOX || P.geom == RT_GEOM_RECT) && !(P.flags & RT_PRIM_MEDIUM);
+}
+RT_HD float fp32_step(float f, bool up) {  // the neighbour of a finite f above / below it
+    uint32_t b; memcpy(&b, &f, sizeof(b));
+    if ((b & 0x7fffffffu) == 0u) b = up ? 1u : 0x80000001u;
+    else b += ((b >> 31) == 0u) == up ? 1u : 0xffffffffu;
+    memcpy(&f, &b, sizeof(f));
+    return f;
+}
+// `point` = the f64 point rounded to nearest, `err` = what the rounding left (point_f64 - point), `n` the surface normal,
+// `leaves_along_n`: the new ray leaves on the normal's side.
+RT_HD V3 side_of_surface(V3 point, V3 err, V3 n, bool leaves_along_n) {
+    float p[3] = {point.x, point.y, point.z};
+    const float e[3] = {err.x, err.y, err.z}, m[3] = {n.x, n.y, n.z};
+    for (int c = 0; c < 3; ++c) {
+        const bool up = (m[c] > 0.0f) == leaves_along_n;                       // the direction of "outside" on this axis
+        if (m[c] != 0.0f && e[c] != 0.0f && (e[c] > 0.0f) == up) p[c] = fp32_step(p[c], up);  // (NaN: every comparison false)
+    }
+    return v3(p[0], p[1], p[2]);
+}
+
 // The rest of the IntersectionPoint for an accepted (prim, t, side), carried back out through the
 // wrappers (Rotated rotates point / normal / in_vec by +angle, shape.rs:378-383; Translated adds the
 // offset to the point, shape.rs:364-367).
@@ -551,6 +585,7 @@ RT_HD void prim_surface(const SceneView& S, const rt_prim& P, uint32_t prim, V3 
     }
     if (P.flags & RT_PRIM_FLIP) n = n * -1.0;
     h.point = v3(pt); h.normal = v3(n); h.u = (float)u; h.v = (float)v;
+    h.point_err = plane_off_grid(P) ? v3(pt - d3(h.point)) : v3(0.0f, 0.0f, 0.0f);
 }
 RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float time, float t, int side, Hit& h) {
     prim_surface(S, S.prims[prim], prim, o, d, time, t, side, true, true, h);
@@ -1268,6 +1303,7 @@ RT_HD bool shade_step(const SceneView& S, Ray& r, V3& thr, const DrawKey& key, b
     if (!sc.scattered) { value = thr * sc.color; return false; }  // lib.rs:92
     thr = thr * sc.color;
     r.o = sc.o; r.d = sc.d;
+    if (plane_off_grid(P)) r.o = side_of_surface(sc.o, h.point_err, h.normal, !(dot(sc.d, h.normal) < 0.0f));
     // lib.rs:103: a path that is still alive after max_reflections segments is black.  A path whose
     // throughput is exactly zero can only ever contribute zero, so it ends here as well.
     if (last_bounce || (thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f)) { value = v3(0.0f, 0.0f, 0.0f); return false; }

@@ -2,7 +2,7 @@
 means clamped to [0, 1]) of many independent renders on each side; the difference of the two sides' averages is judged against
 the scatter between seeds.  The frames are those of tests/golden/make_converged.py (small frame, 4 096 spp, depth 50).
 
-    python tools/bias_check.py oracle <scene> <n> [first seed]    (CPU, here)   -> profiles/bias/<scene>_oracle.json
+    python tools/bias_check.py oracle <scene> <n> [first seed]    (CPU, here)   -> tests/golden/frame_means/<scene>_oracle.json
     python tools/bias_check.py gpu <scene> <n> [first seed]       (GPU box)     -> gpurun_out/bias_<scene>_gpu.json
     python tools/bias_check.py compare <scene> <gpu json>
 """
@@ -29,7 +29,7 @@ def main():
     if mode == "oracle":
         from oracle_lib import OracleScene
         n, first = int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 5001
-        path = os.path.join("profiles", "bias", f"{name}_oracle.json")
+        path = os.path.join("tests", "golden", "frame_means", f"{name}_oracle.json")
         os.makedirs(os.path.dirname(path), exist_ok=True)
         doc = json.load(open(path)) if os.path.exists(path) else {"scene": name, "width": w, "height": h, "spp": SPP, "depth": DEPTH, "means": {}}
         osc, oco = OracleScene.example(name, SCENE_SEED, earth)
@@ -52,7 +52,7 @@ def main():
         json.dump(doc, open(os.path.join("gpurun_out", f"bias_{name}_gpu.json"), "w"), indent=1)
         print(name, "gpu", n, "seeds done")
     else:
-        o = np.array(list(json.load(open(os.path.join("profiles", "bias", f"{name}_oracle.json")))["means"].values()))
+        o = np.array(list(json.load(open(os.path.join("tests", "golden", "frame_means", f"{name}_oracle.json")))["means"].values()))
         g = np.array(list(json.load(open(sys.argv[3]))["means"].values()))
         se = np.sqrt(o.var(0, ddof=1) / len(o) + g.var(0, ddof=1) / len(g))
         print(f"{name}: oracle {len(o)} renders, mean {np.round(o.mean(0), 6)}, seed-to-seed std {np.round(o.std(0, ddof=1), 6)}")
