@@ -541,8 +541,10 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
 // out 3 % darker and the frame 0.34 % (tools/bias_check.py; rounding the origins of the f64 oracle to fp32 shows the same).
 // For those surfaces the origin is therefore rounded to the side of the plane the new ray leaves on: a component whose
 // fp32 value fell short of the f64 point in that direction moves one fp32 step along it.  Axis-aligned planes at fp32
-// coordinates (every wall, every plain box side) are exact and untouched, spheres never meet a ray from within (near root
-// only), and a medium has no surface.
+// coordinates (every wall, the sides of final_scene's boxes) are exact and untouched; the tops of those boxes stand at random
+// f64 heights below 101, half an fp32 ulp there is 4e-6, and the oracle with fp32 origins renders final_scene's frame mean
+// to within 1e-6 of itself: plain boxes are left alone.  Spheres never meet a ray from within (near root only), and a
+// medium has no surface.
 RT_HD bool plane_off_grid(const rt_prim& P) {
     return P.xf_count > 0 && (P.geom == RT_GEOM_BOX || P.geom == RT_GEOM_RECT) && !(P.flags & RT_PRIM_MEDIUM);
 }

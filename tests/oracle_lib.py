@@ -83,6 +83,7 @@ def twin():
             "twin_quantise": (C.c_uint8, [C.c_double]),
             "twin_walk_nodes": (C.c_uint32, [C.POINTER(_abi.rt_scene_desc), _P, C.c_uint32]),
             "twin_set_sample_rays": (None, [_P, C.c_uint64]),
+            "twin_side_of_surface": (None, [_P, _P, C.c_int, C.c_uint64, _P]),
             "twin_traverse_stats": (None, [C.POINTER(_abi.rt_scene_desc), _P, C.c_uint64, C.c_uint64, _P, _P, C.c_uint32]),
             "twin_render": (None, [C.POINTER(_abi.rt_scene_desc), C.POINTER(_abi.rt_camera), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, _P]),
         }

@@ -628,3 +628,40 @@ def test_regrouping_by_sample_rays_keeps_leaves_and_hits(earth):
     assert hits0.tobytes() == hits1.tobytes()
     assert work1[0] < 0.85 * work0[0] and work1[1] == work0[1] and work1[2] == work0[2], (work0, work1)   # box tests; leaves reached and primitive tests as before
     assert np.array_equal(_walk_nodes(sc), raw0)                                                         # without sample rays: by areas again
+
+
+def test_origins_are_rounded_to_the_side_a_ray_leaves_on():
+    """side_of_surface (rt_core.h): the fp32 origin of a ray that leaves a plane off the fp32 grid lies on the leaving side of
+    the f64 point in every component the normal has, at most one fp32 step from the nearest rounding; components the normal
+    lacks, exact values, zeros and NaNs keep the nearest rounding."""
+    tw = twin()
+    rng = np.random.default_rng(11)
+    n = 4000
+    pts = rng.uniform(-600.0, 600.0, (n, 3))
+    pts[:50] = np.round(pts[:50])                # exactly representable
+    pts[50:60, 0] = 0.0                          # zeros
+    pts[60:70, 1] = rng.uniform(-1e-14, 1e-14, 10)   # residues around zero: representable in fp32 as they are
+    for normal in ([0.9659258, 0.0, -0.2588190], [-0.30901699, 0.0, 0.95105652], [0.0, 1.0, 0.0]):
+        nv = np.array(normal, np.float32)
+        for along in (1, 0):
+            out = np.zeros((n, 3), np.float32)
+            p = np.ascontiguousarray(pts)
+            tw.twin_side_of_surface(p.ctypes.data, nv.ctypes.data, along, n, out.ctypes.data)
+            near = pts.astype(np.float32)
+            s = np.sign(nv.astype(np.float64)) * (1.0 if along else -1.0)
+            for c in range(3):
+                moved = out[:, c] != near[:, c]
+                if s[c] == 0.0:
+                    assert not moved.any()
+                    continue
+                assert ((out[:, c].astype(np.float64) - pts[:, c]) * s[c] >= 0.0).all()          # on the leaving side
+                step = np.abs(np.nextafter(near[:, c], np.float32(np.inf) * np.float32(s[c])) - near[:, c])
+                assert (np.abs(out[:, c] - near[:, c]) <= step).all()                               # one step at most
+                exact = near[:, c].astype(np.float64) == pts[:, c]
+                assert not (moved & exact).any()
+                assert moved.sum() > n // 4                                                         # about half of the inexact ones
+    bad = np.array([[np.nan, 1.0, np.inf]])
+    out = np.zeros((1, 3), np.float32)
+    nv = np.array([1.0, 1.0, 1.0], np.float32)
+    tw.twin_side_of_surface(bad.ctypes.data, nv.ctypes.data, 1, 1, out.ctypes.data)
+    assert np.isnan(out[0, 0]) and out[0, 1] == 1.0 and np.isinf(out[0, 2])

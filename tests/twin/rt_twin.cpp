@@ -224,6 +224,15 @@ uint32_t twin_trace_sample(const rt_scene_desc* D, const rt_camera* cam, uint32_
 }
 
 float twin_perlin3(const uint8_t* perm256, float x, float y, float z) { return perlin3(perm256, v3(x, y, z)); }
+// side_of_surface for n points: f64 points in, the fp32 origins a new ray gets out
+void twin_side_of_surface(const double* points, const float* normal, int leaves_along_n, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const D3 p = d3(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
+        const V3 f = v3(p);
+        const V3 r = side_of_surface(f, v3(p - d3(f)), v3(normal[0], normal[1], normal[2]), leaves_along_n != 0);
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+}
 void twin_random_unit_vector(float u_phi, float u_z, float* out) { V3 r = random_unit_vector(u_phi, u_z); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
 void twin_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) {
     U4 r = philox4x32_10(c[0], c[1], c[2], c[3], k[0], k[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
