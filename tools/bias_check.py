@@ -13,7 +13,7 @@ import time
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')
 import numpy as np
-FRAMES = {"cornell": (96, 96), "perlin": (128, 72), "cornell_smoke": (96, 96), "final_scene": (96, 96)}
+FRAMES = {"cornell": (96, 96), "perlin": (128, 72), "cornell_smoke": (96, 96), "final_scene": (96, 96), "random_spheres": (96, 54)}
 SPP, DEPTH, SCENE_SEED = 4096, 50, 1
 
 
