@@ -75,7 +75,7 @@ FRAME_MEANS = os.path.join(GOLDEN, "frame_means")
 GPU_SEEDS = 24
 
 
-@pytest.mark.parametrize("name", ["cornell", "perlin", "cornell_smoke", "final_scene"])
+@pytest.mark.parametrize("name", ["cornell", "perlin", "cornell_smoke", "final_scene", "random_spheres"])
 def test_frame_mean_over_many_seeds_matches_the_oracle(name, earth):
     import json
     with open(os.path.join(FRAME_MEANS, f"{name}_oracle.json")) as fh:
