@@ -41,7 +41,7 @@ def main():
     mode, name = sys.argv[1], sys.argv[2]
     w, h, k = FRAMES[name]
     if mode == "compare":
-        o, g = np.load(os.path.join(FIXTURES, f"{name}_oracle.npz"))["blocks"], np.load(sys.argv[3])["blocks"]
+        o, g = (np.asarray(a, np.float64) for a in (np.load(os.path.join(FIXTURES, f"{name}_oracle.npz"))["blocks"], np.load(sys.argv[3])["blocks"]))
         diff, se, mean, z = compare(o, g)
         print(f"{name}: {len(g)} gpu against {len(o)} oracle renders; frame mean gpu - oracle {np.round(diff, 6)} = {np.round(diff / se, 2)} standard errors, {np.round(100 * diff / mean, 3)} %")
         print(f"{name}: block z-scores ({z.shape[0]}x{z.shape[1]} blocks x 3 channels): mean square {np.mean(z ** 2):.3f}, largest |z| {np.abs(z).max():.2f}")
