@@ -86,10 +86,7 @@ def _block_means(m, k):
 
 @pytest.mark.parametrize("name", ["cornell", "perlin", "cornell_smoke", "final_scene", "random_spheres"])
 def test_many_seeds_on_both_sides_agree_over_the_frame_and_block_by_block(name, earth):
-    path = os.path.join(FRAME_MEANS, f"{name}_oracle.npz")
-    if not os.path.exists(path):
-        pytest.skip("fixture being made")
-    fx = np.load(path)
+    fx = np.load(os.path.join(FRAME_MEANS, f"{name}_oracle.npz"))
     o = fx["blocks"].astype(np.float64)
     assert len(o) >= 6, "too few oracle renders in the fixture"
     w, h, k, spp, depth = (int(fx[key]) for key in ("width", "height", "block", "spp", "depth"))
