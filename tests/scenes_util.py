@@ -190,3 +190,32 @@ def far_root_variant_scene():
     co = dict(aperture=0.05, aspect_ratio=1.5, focus_distance=9.0, looking_at=(0.0, 1.0, 0.0), origin=(0.0, 2.0, 9.0), shutter_close=1.0, shutter_open=0.0,
               vfov=30.0, vup=(0.0, 1.0, 0.0))
     return objects, (0.7, 0.8, 1.0), co
+
+
+def zoo_room():
+    """A Cornell room holding the wrapped shapes and the materials side by side (not one of the reference's scenes): boxes behind
+    rotations about each axis and behind a translation off the fp32 grid, a tilted two-sided panel, a glass box, a metal box, a
+    medium in a rotated box, a moving sphere, a metal sphere.  For the many-seed comparison of GPU and oracle."""
+    import raytracing_amd as rt
+    T, M, S = rt.Texture, rt.Material, rt.Shape
+    X, Y, Z = 0, 1, 2
+    white, red, green = (M.Lambertian(T.SolidColor(c)) for c in ((0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15)))
+    objects = [
+        rt.Object(S.rectangle((0, 0, 0), (0, 555, 555)), red),
+        rt.Object(S.rectangle((555, 0, 0), (555, 555, 555)).flipped(), green),
+        rt.Object(S.rectangle((0, 0, 0), (555, 0, 555)), white),
+        rt.Object(S.rectangle((0, 555, 0), (555, 555, 555)).flipped(), white),
+        rt.Object(S.rectangle((0, 0, 555), (555, 555, 555)).flipped(), white),
+        rt.Object(S.rectangle((163, 554, 177), (393, 554, 382)), M.DiffuseLight(T.SolidColor((12, 12, 12)))),
+        rt.Object(S.new_box((0, 0, 0), (120, 250, 120)).rotated(Y, 22.0).translated((330.3, 0.0, 340.7)), white),              # the cornell kind, off the grid
+        rt.Object(S.new_box((0, 0, 0), (100, 100, 100)).rotated(X, 17.0).translated((60.1, 40.2, 300.3)), M.Metal((0.8, 0.8, 0.9), 0.3)),
+        rt.Object(S.new_box((0, 0, 0), (90, 90, 90)).rotated(Z, -12.0).rotated(Y, 31.0).translated((390.5, 30.25, 120.6)), M.glass()),
+        rt.Object(S.new_box((0, 0, 0), (110, 60, 110)).translated((200.33, 0.0, 90.77)), white),                               # translated only
+        rt.Object(S.rectangle((0, 0, 0), (140, 180, 0)).rotated(Y, 40.0).rotated(X, -10.0).translated((150.2, 120.4, 380.6)), green),   # a tilted panel, hit from both sides
+        rt.Object(S.ConstantMedium(S.new_box((0, 0, 0), (100, 140, 100)).rotated(Y, -25.0).translated((230.7, 0.0, 230.9)), 0.02), M.Isotropic(T.SolidColor((0.9, 0.9, 0.9)))),
+        rt.Object(S.sphere(35.0, (0.0, (470.0, 300.0, 250.0)), (1.0, (470.0, 330.0, 250.0))), red),
+        rt.Object(S.Sphere((110.0, 260.0, 160.0), 45.0), M.Metal((0.9, 0.8, 0.7), 0.05)),
+    ]
+    co = dict(aperture=0.0, aspect_ratio=1.0, focus_distance=10.0, looking_at=(278.0, 278.0, 0.0), origin=(278.0, 278.0, -800.0), shutter_close=1.0, shutter_open=0.0,
+              vfov=40.0, vup=(0.0, 1.0, 0.0))
+    return objects, (0.0, 0.0, 0.0), co

@@ -68,7 +68,8 @@ def test_converged_image_matches_the_oracle(name, earth):
 # One GPU render against one oracle render resolves a bias of about a per cent of the frame mean.  The fixtures
 # tests/golden/frame_means/<scene>_oracle.npz (made by tools/bias_check.py) hold, for many oracle renders of the same small
 # frame with independent seeds, the means of the frame's 8 x 8 blocks (per channel, of the per-pixel means clamped to [0, 1]);
-# the GPU renders the frame with as many seeds of its own.  Asserted: the two sides' average frame means agree within 4
+# the GPU renders the frame with as many seeds of its own (the five example scenes, and a room of wrapped shapes and all
+# materials that the examples do not contain, at 2 048 spp).  Asserted: the two sides' average frame means agree within 4
 # standard errors of their difference (estimated from the scatter between seeds; a standard error is at most 0.05 % of the
 # mean), and block by block the difference of the averages, in units of its standard error (variance pooled over both sides),
 # behaves like noise: mean square at most 1.4 over the frame's blocks (1.0 expected, 0.07 its own scatter) and no block beyond
@@ -84,13 +85,18 @@ def _block_means(m, k):
     return c.reshape(h // k, k, w // k, k, 3).mean(axis=(1, 3))
 
 
-@pytest.mark.parametrize("name", ["cornell", "perlin", "cornell_smoke", "final_scene", "random_spheres"])
+@pytest.mark.parametrize("name", ["cornell", "perlin", "cornell_smoke", "final_scene", "random_spheres", "zoo_room"])
 def test_many_seeds_on_both_sides_agree_over_the_frame_and_block_by_block(name, earth):
     fx = np.load(os.path.join(FRAME_MEANS, f"{name}_oracle.npz"))
     o = fx["blocks"].astype(np.float64)
     assert len(o) >= 6, "too few oracle renders in the fixture"
     w, h, k, spp, depth = (int(fx[key]) for key in ("width", "height", "block", "spp", "depth"))
-    sc, co = rt.Scene.example(name, int(fx["scene_seed"]), earth if name == "final_scene" else None)
+    if name == "zoo_room":   # (not an example of the reference: the wrapped shapes and the materials side by side, tests/scenes_util.py)
+        from scenes_util import zoo_room
+        objects, background, co_kw = zoo_room()
+        sc, co = rt.Scene(objects, background), rt.CameraOptions(**co_kw)
+    else:
+        sc, co = rt.Scene.example(name, int(fx["scene_seed"]), earth if name == "final_scene" else None)
     cam, io = rt.Camera(co), rt.ImageOptions(h, w, spp, depth)
     g = []
     for seed in range(7001, 7001 + GPU_SEEDS):
