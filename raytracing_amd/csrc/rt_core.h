@@ -545,8 +545,12 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
 // f64 heights below 101, half an fp32 ulp there is 4e-6, and the oracle with fp32 origins renders final_scene's frame mean
 // to within 1e-6 of itself: plain boxes are left alone.  Spheres never meet a ray from within (near root only), and a
 // medium has no surface.
+// (The same holds for a sphere that is also hit from within, RT_PRIM_BOTH_ROOTS, which is not the reference's behaviour: its
+// far root is the surface a ray has just left.)
 RT_HD bool plane_off_grid(const rt_prim& P) {
-    return P.xf_count > 0 && (P.geom == RT_GEOM_BOX || P.geom == RT_GEOM_RECT) && !(P.flags & RT_PRIM_MEDIUM);
+    if (P.flags & RT_PRIM_MEDIUM) return false;
+    if (P.geom == RT_GEOM_BOX || P.geom == RT_GEOM_RECT) return P.xf_count > 0;
+    return (P.flags & RT_PRIM_BOTH_ROOTS) != 0;
 }
 RT_HD float fp32_step(float f, bool up) {  // the neighbour of a finite f above / below it
     uint32_t b; memcpy(&b, &f, sizeof(b));
