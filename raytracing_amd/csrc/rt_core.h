@@ -28,6 +28,14 @@
 #else
 #define RT_HD inline
 #endif
+// "Some lane of the wave" on the device, the condition itself on the host: a rare piece of work behind `if (RT_ANY_LANE(c)) if (c)`
+// costs the waves that have none of it a scalar branch, where a plain `if (c)` of a few dozen instructions is turned into
+// selects that every lane pays for.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#else
+#define RT_ANY_LANE(c) (c)
+#endif
 
 // Optional work counters for host-side analysis builds (empty in the product).
 #ifndef RT_COUNT
@@ -122,6 +130,7 @@ struct SceneView {
     // array lengths, for the kernels that copy a small scene's tables into LDS (texels stay in global memory)
     uint32_t n_spheres, n_rects, n_boxes, n_xforms, n_textures, n_images, n_perm_tables;
     uint32_t lds_scene_bytes;  // bytes those tables take in LDS behind the node array (each 16-byte aligned); 0 = leave them in global memory
+    uint32_t side_rounding;    // some primitive's hit points need side_of_surface (scene_needs_side_rounding); the kernels come in two builds, with and without
 };
 
 // Rectangles and boxes as the kernels hold them: every f64 coordinate of the description as an fp32 value `hi` and an
@@ -453,7 +462,7 @@ struct Hit {  // IntersectionPoint (shape.rs:539-550)
     float t, u, v;
     V3 point, normal, in_vec;
     uint32_t prim;
-    V3 point_err = v3(0.0f, 0.0f, 0.0f);  // the f64 point minus `point`, for the surfaces where shade_step needs it (see side_of_surface); zero elsewhere
+    uint32_t point_side = 0;  // where the f64 point lies from `point`, for the surfaces where shade_step needs it (see side_of_surface): bit 2c = above on axis c, bit 2c + 1 = below; zero elsewhere
 };
 
 // Point, normal and surface coordinates in the shape's frame for an accepted (t, side).  Runs once per
@@ -552,6 +561,10 @@ RT_HD bool plane_off_grid(const rt_prim& P) {
     if (P.geom == RT_GEOM_BOX || P.geom == RT_GEOM_RECT) return P.xf_count > 0;
     return (P.flags & RT_PRIM_BOTH_ROOTS) != 0;
 }
+inline bool scene_needs_side_rounding(const rt_scene_desc* D) {  // (host side)
+    for (uint32_t i = 0; i < D->n_prims; ++i) if (plane_off_grid(D->prims[i])) return true;
+    return false;
+}
 RT_HD float fp32_step(float f, bool up) {  // the neighbour of a finite f above / below it
     uint32_t b; memcpy(&b, &f, sizeof(b));
     if ((b & 0x7fffffffu) == 0u) b = up ? 1u : 0x80000001u;
@@ -559,14 +572,14 @@ RT_HD float fp32_step(float f, bool up) {  // the neighbour of a finite f above 
     memcpy(&f, &b, sizeof(f));
     return f;
 }
-// `point` = the f64 point rounded to nearest, `err` = what the rounding left (point_f64 - point), `n` the surface normal,
-// `leaves_along_n`: the new ray leaves on the normal's side.
-RT_HD V3 side_of_surface(V3 point, V3 err, V3 n, bool leaves_along_n) {
+// `point` = the f64 point rounded to nearest, `side` = where the f64 point lies from it (Hit::point_side; a NaN sets no bit),
+// `n` the surface normal, `leaves_along_n`: the new ray leaves on the normal's side.
+RT_HD V3 side_of_surface(V3 point, uint32_t side, V3 n, bool leaves_along_n) {
     float p[3] = {point.x, point.y, point.z};
-    const float e[3] = {err.x, err.y, err.z}, m[3] = {n.x, n.y, n.z};
+    const float m[3] = {n.x, n.y, n.z};
     for (int c = 0; c < 3; ++c) {
         const bool up = (m[c] > 0.0f) == leaves_along_n;                       // the direction of "outside" on this axis
-        if (m[c] != 0.0f && e[c] != 0.0f && (e[c] > 0.0f) == up) p[c] = fp32_step(p[c], up);  // (NaN: every comparison false)
+        if (m[c] != 0.0f && ((side >> (2 * c + (up ? 0 : 1))) & 1u)) p[c] = fp32_step(p[c], up);
     }
     return v3(p[0], p[1], p[2]);
 }
@@ -591,7 +604,12 @@ RT_HD void prim_surface(const SceneView& S, const rt_prim& P, uint32_t prim, V3 
     }
     if (P.flags & RT_PRIM_FLIP) n = n * -1.0;
     h.point = v3(pt); h.normal = v3(n); h.u = (float)u; h.v = (float)v;
-    h.point_err = plane_off_grid(P) ? v3(pt - d3(h.point)) : v3(0.0f, 0.0f, 0.0f);
+    h.point_side = 0;
+    const bool off_grid = S.side_rounding != 0u && plane_off_grid(P);
+    if (RT_ANY_LANE(off_grid)) if (off_grid) {
+        const D3 e = pt - d3(h.point);
+        h.point_side = (e.x > 0.0 ? 1u : 0u) | (e.x < 0.0 ? 2u : 0u) | (e.y > 0.0 ? 4u : 0u) | (e.y < 0.0 ? 8u : 0u) | (e.z > 0.0 ? 16u : 0u) | (e.z < 0.0 ? 32u : 0u);
+    }
 }
 RT_HD void prim_surface(const SceneView& S, uint32_t prim, V3 o, V3 d, float time, float t, int side, Hit& h) {
     prim_surface(S, S.prims[prim], prim, o, d, time, t, side, true, true, h);
@@ -1309,7 +1327,7 @@ RT_HD bool shade_step(const SceneView& S, Ray& r, V3& thr, const DrawKey& key, b
     if (!sc.scattered) { value = thr * sc.color; return false; }  // lib.rs:92
     thr = thr * sc.color;
     r.o = sc.o; r.d = sc.d;
-    if (plane_off_grid(P)) r.o = side_of_surface(sc.o, h.point_err, h.normal, !(dot(sc.d, h.normal) < 0.0f));
+    if (RT_ANY_LANE(h.point_side != 0u)) if (h.point_side != 0u) r.o = side_of_surface(sc.o, h.point_side, h.normal, !(dot(sc.d, h.normal) < 0.0f));
     // lib.rs:103: a path that is still alive after max_reflections segments is black.  A path whose
     // throughput is exactly zero can only ever contribute zero, so it ends here as well.
     if (last_bounce || (thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f)) { value = v3(0.0f, 0.0f, 0.0f); return false; }

@@ -180,9 +180,12 @@ __device__ __forceinline__ const T* stage_table(const T* src, uint32_t count, un
     at += lds_align16(words * 4u);
     return count ? out : src;
 }
-template <bool NODES_IN_LDS>
+// SIDES: the build of the kernel for scenes with hit points that need side_of_surface (rt_core.h); the other build has that
+// code folded away (its mere presence cost the scenes without such surfaces 1 to 2 %: registers, spills).
+template <bool NODES_IN_LDS, bool SIDES = false>
 __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds) {
     SceneView V = S;
+    V.side_rounding = SIDES ? 1u : 0u;
     if (NODES_IN_LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(S.bvh);
         for (uint32_t k = threadIdx.x; k < 2u * (S.n_bvh_nodes + 1u); k += blockDim.x) lds[k] = src[k];  // with the sentinel slot
@@ -413,7 +416,7 @@ __device__ __forceinline__ bool closest_hit_scan(const SceneView& S, const Ray& 
     return w.found;
 }
 
-template <int MODE>
+template <int MODE, bool SIDES>
 __global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
     extern __shared__ uint4 lds_nodes[];
@@ -425,7 +428,7 @@ __global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_sha
     // of the two kernels' instruction issue (final_scene: 507 -> 573 Msamples/s; raising the traversal's priority instead
     // changed nothing).  On its own the kernel is a few per cent slower with the priority raised, so it is only raised there.
     if (MODE == SHADE_HITS && P.overlapped) __builtin_amdgcn_s_setprio(RT_SHADE_PRIO);
-    const SceneView S = stage_nodes<MODE != SHADE_HITS>(S0, lds_nodes);
+    const SceneView S = stage_nodes<MODE != SHADE_HITS, SIDES>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t base = blockIdx.x * RT_SHADE_BS; base < count; base += gridDim.x * RT_SHADE_BS) {
@@ -502,11 +505,11 @@ __global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_sha
 }
 
 // Every ray left in the queue runs the remaining iterations of ray_color in one launch.
-template <bool NODES_IN_LDS>
+template <bool NODES_IN_LDS, bool SIDES>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_tail(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr, float4* values, uint32_t* segment_counter,
                                                      uint32_t first_bounce) {
     extern __shared__ uint4 lds_nodes[];
-    const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
+    const SceneView S = stage_nodes<NODES_IN_LDS, SIDES>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     uint32_t segments = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -896,6 +899,7 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     V.n_spheres = D->n_spheres; V.n_rects = D->n_rects; V.n_boxes = D->n_boxes; V.n_xforms = D->n_xforms;
     V.n_textures = D->n_textures; V.n_images = D->n_images; V.n_perm_tables = D->n_perm_tables;
     V.lds_scene_bytes = 0;
+    V.side_rounding = scene_needs_side_rounding(D) ? 1u : 0u;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
     for (auto& x : sc->side_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
@@ -923,9 +927,10 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_traverse<true>));
         if (e == hipSuccess && fa.sharedSizeBytes != 0) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array"); }
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tail<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade<SHADE_WALK>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade<SHADE_SCAN>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
+        const void* const walkers[] = {reinterpret_cast<const void*>(&k_tail<true, false>), reinterpret_cast<const void*>(&k_tail<true, true>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_WALK, false>), reinterpret_cast<const void*>(&k_shade<SHADE_WALK, true>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true>)};
+        for (const void* f : walkers) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
     }
     if ((st = resolve_scratch(device)) != RT_OK) { rt_scene_destroy(sc); return st; }
@@ -1199,6 +1204,12 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     struct Half {
         hipStream_t stream; PassParams P; RayQueue q[2]; uint2* hits; uint32_t* counts; float4* values; int cur;
     };
+    const bool sides = sc->view.side_rounding != 0u;  // (which build of the shading kernels: see stage_nodes)
+    const auto tail_lds = sides ? &k_tail<true, true> : &k_tail<true, false>;
+    const auto tail_global = sides ? &k_tail<false, true> : &k_tail<false, false>;
+    const auto shade_scan = sides ? &k_shade<SHADE_SCAN, true> : &k_shade<SHADE_SCAN, false>;
+    const auto shade_walk = sides ? &k_shade<SHADE_WALK, true> : &k_shade<SHADE_WALK, false>;
+    const auto shade_hits = sides ? &k_shade<SHADE_HITS, true> : &k_shade<SHADE_HITS, false>;
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
             hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
@@ -1207,10 +1218,11 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     };
     auto launch_tail = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
-            hipLaunchKernelGGL(k_tail<true>, dim3(trav_grid), dim3(RT_TRAV_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values,
-                               h.counts + depth + 1, b);
+            hipLaunchKernelGGL(tail_lds, dim3(trav_grid), dim3(RT_TRAV_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b,
+                               h.values, h.counts + depth + 1, b);
         else
-            hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(RT_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values, h.counts + depth + 1, b);
+            hipLaunchKernelGGL(tail_global, dim3(grid), dim3(RT_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.values,
+                               h.counts + depth + 1, b);
     };
     // max_reflections == 0: ray_color's loop body never runs and every sample is black (lib.rs:89, :103)
     for (uint64_t s0 = 0; s0 < spp && depth > 0; s0 += S) {
@@ -1272,14 +1284,14 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 }
                 if (n_halves == 1 && (st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
                 if (fused && scan)
-                    hipLaunchKernelGGL(k_shade<SHADE_SCAN>, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
-                                       h.counts + b, h.counts + b + 1, h.values, b);
+                    hipLaunchKernelGGL(shade_scan, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P,
+                                       h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + 1, h.values, b);
                 else if (fused)
-                    hipLaunchKernelGGL(k_shade<SHADE_WALK>, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
-                                       h.counts + b, h.counts + b + 1, h.values, b);
+                    hipLaunchKernelGGL(shade_walk, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P,
+                                       h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + 1, h.values, b);
                 else
-                    hipLaunchKernelGGL(k_shade<SHADE_HITS>, dim3(shade_grid[k]), dim3(RT_SHADE_BS), 0, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
-                                       h.counts + b, h.counts + b + 1, h.values, b);
+                    hipLaunchKernelGGL(shade_hits, dim3(shade_grid[k]), dim3(RT_SHADE_BS), 0, h.stream, sc->view, h.P,
+                                       h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + 1, h.values, b);
                 if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
                 h.cur ^= 1;
             }

@@ -37,6 +37,7 @@ struct TwinScene {
         make_device_shapes(D, rects, boxes);
         V.prims = D->prims; V.spheres = D->spheres; V.rects = rects.data(); V.boxes = boxes.data(); V.xforms = D->xforms;
         make_shade_records(D, shade);
+        V.side_rounding = scene_needs_side_rounding(D) ? 1u : 0u;
         V.shade = shade.data(); V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
         if (with_nodes) make_walk_nodes(D, nodes, g_sample_rays.size() ? &g_sample_rays : nullptr);
         V.bvh = nodes.data();
@@ -229,7 +230,9 @@ void twin_side_of_surface(const double* points, const float* normal, int leaves_
     for (uint64_t i = 0; i < n; ++i) {
         const D3 p = d3(points[3 * i], points[3 * i + 1], points[3 * i + 2]);
         const V3 f = v3(p);
-        const V3 r = side_of_surface(f, v3(p - d3(f)), v3(normal[0], normal[1], normal[2]), leaves_along_n != 0);
+        const D3 e = p - d3(f);
+        const uint32_t side = (e.x > 0.0 ? 1u : 0u) | (e.x < 0.0 ? 2u : 0u) | (e.y > 0.0 ? 4u : 0u) | (e.y < 0.0 ? 8u : 0u) | (e.z > 0.0 ? 16u : 0u) | (e.z < 0.0 ? 32u : 0u);
+        const V3 r = side_of_surface(f, side, v3(normal[0], normal[1], normal[2]), leaves_along_n != 0);
         out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
     }
 }
