@@ -416,11 +416,20 @@ __device__ __forceinline__ bool closest_hit_scan(const SceneView& S, const Ray& 
     return w.found;
 }
 
+// A scanned bounce (SHADE_SCAN) runs in workgroups of 256: its waves do a whole segment's work between two barriers and a CU
+// holds sixteen of them at the kernel's 128 registers, so four workgroups per CU are in four different phases (load, scan,
+// shade, store) where two of 512 are in two (cornell +2 %, cornell_smoke +7 %, perlin unchanged; its rate of atomics,
+// 58 M/s per queue end on cornell, stays below what one address takes; 128 threads: 15 to 30 % slower).
+#ifndef RT_SCAN_GRID_PER_CU
+#define RT_SCAN_GRID_PER_CU 8u  // workgroups of a scanned bounce per CU (four are resident at a time)
+#endif
+__host__ __device__ constexpr uint32_t shade_bs(int mode) { return mode == 2 /* SHADE_SCAN */ ? 256u : RT_SHADE_BS; }
 template <int MODE, bool SIDES>
-__global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+__global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
+    constexpr uint32_t BS = shade_bs(MODE);
     extern __shared__ uint4 lds_nodes[];
-    __shared__ uint32_t wave_cnt[2][RT_SHADE_BS / 64];
+    __shared__ uint32_t wave_cnt[2][BS / 64];
     __shared__ uint32_t block_base[2];
     // Shading waves that run beside the traversal workgroup of the pass's other half (two streams) spend most of their time
     // waiting on queue memory: at a higher issue priority their few instructions go ahead of the traversal's whenever they
@@ -431,7 +440,7 @@ __global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_sha
     const SceneView S = stage_nodes<MODE != SHADE_HITS, SIDES>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * RT_SHADE_BS; base < count; base += gridDim.x * RT_SHADE_BS) {
+    for (uint32_t base = blockIdx.x * BS; base < count; base += gridDim.x * BS) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false, to_front = false;
         Ray r; V3 thr; uint32_t path = 0, pixel = 0;
@@ -489,7 +498,7 @@ __global__ void __launch_bounds__(RT_SHADE_BS, MODE != SHADE_HITS ? 4 : 5) k_sha
         if (threadIdx.x < 2) {
             const uint32_t e = threadIdx.x;
             uint32_t total = 0;
-            for (int w = 0; w < RT_SHADE_BS / 64; ++w) { uint32_t c = wave_cnt[e][w]; wave_cnt[e][w] = total; total += c; }
+            for (int w = 0; w < (int)(BS / 64); ++w) { uint32_t c = wave_cnt[e][w]; wave_cnt[e][w] = total; total += c; }
             block_base[e] = total ? atomicAdd(next_count + e * P.n_counts, total) : 0u;
         }
         __syncthreads();
@@ -1249,12 +1258,13 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             HIP_TRY(hipEventRecord(sc->ev_fork, stream));
             for (int k = 1; k < n_halves; ++k) HIP_TRY(hipStreamWaitEvent(sc->side_stream[k - 1], sc->ev_fork, 0));
         }
-        uint32_t grid[RT_MAX_PARTS], shade_grid[RT_MAX_PARTS], trav_grid[RT_MAX_PARTS];
+        uint32_t grid[RT_MAX_PARTS], shade_grid[RT_MAX_PARTS], scan_grid[RT_MAX_PARTS], trav_grid[RT_MAX_PARTS];
         for (int k = 0; k < n_halves; ++k) {
             Half& h = half[k];
             const uint32_t grid_full = (h.P.n_paths + RT_BS - 1) / RT_BS;
             grid[k] = std::min(grid_full, max_grid);
             shade_grid[k] = std::min((h.P.n_paths + RT_SHADE_BS - 1) / RT_SHADE_BS, max_grid * RT_BS / RT_SHADE_BS);
+            scan_grid[k] = std::min((h.P.n_paths + shade_bs(SHADE_SCAN) - 1) / shade_bs(SHADE_SCAN), sc->n_cu * RT_SCAN_GRID_PER_CU);
             trav_grid[k] = std::min((h.P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, sc->n_cu);
             if (k == 0 && (st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
             hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, h.stream, h.P, h.q[0], h.counts, n_counts);
@@ -1284,7 +1294,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 }
                 if (n_halves == 1 && (st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
                 if (fused && scan)
-                    hipLaunchKernelGGL(shade_scan, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P,
+                    hipLaunchKernelGGL(shade_scan, dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes, h.stream, sc->view, h.P,
                                        h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + 1, h.values, b);
                 else if (fused)
                     hipLaunchKernelGGL(shade_walk, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P,
