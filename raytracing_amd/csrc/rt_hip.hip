@@ -416,6 +416,37 @@ __device__ __forceinline__ bool closest_hit_scan(const SceneView& S, const Ray& 
     return w.found;
 }
 
+// Which end of the next queue a scattered ray of a scanned scene goes to.  The leaves whose test is long (anything but a
+// plain sphere, rectangle or box: shapes behind wrappers, media -- the f64 path of prim_t) are tried by a wave iff one of its
+// lanes meets the leaf's box, so a wave of rays that all pass such leaves by skips their tests altogether: rays that meet the
+// box of at least one of them go to the front of the queue, the others to the back, and a wave of the next bounce holds
+// (but for the one at the boundary) rays of one kind.  The test is the scan's own box test with the interval still
+// unbounded above, so "passes by" is certain; it costs a reciprocal direction and one slab test per such leaf.  Scenes
+// without such leaves keep the key of the general case (up or down along the camera's up axis).  A queue's order never
+// changes the image.
+#ifndef RT_SCAN_SORT
+#define RT_SCAN_SORT 1
+#endif
+__device__ __forceinline__ bool scan_queue_end(const SceneView& S, const PassParams& P, const Ray& r) {
+    const bool up = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
+    if (!RT_SCAN_SORT) return up;
+    const V3 inv_c = walk_cap(ray_inv(r.d));
+    const V3 oi = v3(r.o.x * inv_c.x, r.o.y * inv_c.y, r.o.z * inv_c.z);
+    bool long_leaves = false, meets = false;
+    const uint32_t n = S.n_bvh_nodes * RT_NODE_STRIDE;
+    for (uint32_t pos = 0; pos < n;) {  // (the same position in every lane)
+        const WalkNode& N = node_at(S.bvh, pos);
+        const uint32_t leaf = __builtin_amdgcn_readfirstlane(N.prim);
+        if (leaf < RT_NODE_LEAF) { pos += RT_NODE_STRIDE; continue; }
+        if (!(leaf & (RT_NODE_PLAIN_SPHERE | RT_NODE_PLAIN_BOX | RT_NODE_PLAIN_RECT))) {
+            long_leaves = true;
+            meets = meets || node_hit(N, inv_c, oi, 0.001f, RT_WALK_FAR);
+        }
+        pos = __builtin_amdgcn_readfirstlane(N.skip);
+    }
+    return long_leaves ? meets && !has_negative_zero(r.d) : up;
+}
+
 // A scanned bounce (SHADE_SCAN) runs in workgroups of 256: its waves do a whole segment's work between two barriers and a CU
 // holds sixteen of them at the kernel's 128 registers, so four workgroups per CU are in four different phases (load, scan,
 // shade, store) where two of 512 are in two (cornell +2 %, cornell_smoke +7 %, perlin unchanged; its rate of atomics,
@@ -465,8 +496,8 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_
                 V3 value;
                 alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value);
                 if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
-                else to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
             }
+            to_front = alive && scan_queue_end(S, P, r);
         } else if (i < count) {
             const uint32_t at = queue_slot(i, n_front, P.n_paths);
             const NtF4 a_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od0[at])), b_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od1[at])),
