@@ -422,29 +422,21 @@ __device__ __forceinline__ bool closest_hit_scan(const SceneView& S, const Ray& 
 // box of at least one of them go to the front of the queue, the others to the back, and a wave of the next bounce holds
 // (but for the one at the boundary) rays of one kind.  The test is the scan's own box test with the interval still
 // unbounded above, so "passes by" is certain; it costs a reciprocal direction and one slab test per such leaf.  Scenes
-// without such leaves keep the key of the general case (up or down along the camera's up axis).  A queue's order never
-// changes the image.
-#ifndef RT_SCAN_SORT
-#define RT_SCAN_SORT 1
-#endif
-__device__ __forceinline__ bool scan_queue_end(const SceneView& S, const PassParams& P, const Ray& r) {
-    const bool up = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
-    if (!RT_SCAN_SORT) return up;
+// without such leaves run the build of the kernel without this code (LONG_LEAVES = false: the key of the general case, up
+// or down along the camera's up axis; the code's mere presence cost perlin 6 %).  A queue's order never changes the image.
+__device__ __forceinline__ bool scan_queue_end(const SceneView& S, const Ray& r) {
     const V3 inv_c = walk_cap(ray_inv(r.d));
     const V3 oi = v3(r.o.x * inv_c.x, r.o.y * inv_c.y, r.o.z * inv_c.z);
-    bool long_leaves = false, meets = false;
+    bool meets = false;
     const uint32_t n = S.n_bvh_nodes * RT_NODE_STRIDE;
     for (uint32_t pos = 0; pos < n;) {  // (the same position in every lane)
         const WalkNode& N = node_at(S.bvh, pos);
         const uint32_t leaf = __builtin_amdgcn_readfirstlane(N.prim);
         if (leaf < RT_NODE_LEAF) { pos += RT_NODE_STRIDE; continue; }
-        if (!(leaf & (RT_NODE_PLAIN_SPHERE | RT_NODE_PLAIN_BOX | RT_NODE_PLAIN_RECT))) {
-            long_leaves = true;
-            meets = meets || node_hit(N, inv_c, oi, 0.001f, RT_WALK_FAR);
-        }
+        if (!(leaf & (RT_NODE_PLAIN_SPHERE | RT_NODE_PLAIN_BOX | RT_NODE_PLAIN_RECT))) meets = meets || node_hit(N, inv_c, oi, 0.001f, RT_WALK_FAR);
         pos = __builtin_amdgcn_readfirstlane(N.skip);
     }
-    return long_leaves ? meets && !has_negative_zero(r.d) : up;
+    return meets && !has_negative_zero(r.d);
 }
 
 // A scanned bounce (SHADE_SCAN) runs in workgroups of 256: its waves do a whole segment's work between two barriers and a CU
@@ -455,7 +447,7 @@ __device__ __forceinline__ bool scan_queue_end(const SceneView& S, const PassPar
 #define RT_SCAN_GRID_PER_CU 8u  // workgroups of a scanned bounce per CU (four are resident at a time)
 #endif
 __host__ __device__ constexpr uint32_t shade_bs(int mode) { return mode == 2 /* SHADE_SCAN */ ? 256u : RT_SHADE_BS; }
-template <int MODE, bool SIDES>
+template <int MODE, bool SIDES, bool LONG_LEAVES = false>
 __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
     constexpr uint32_t BS = shade_bs(MODE);
@@ -496,8 +488,9 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_
                 V3 value;
                 alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value);
                 if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
+                else if (!LONG_LEAVES) to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
             }
-            to_front = alive && scan_queue_end(S, P, r);
+            if (LONG_LEAVES) to_front = alive && scan_queue_end(S, r);
         } else if (i < count) {
             const uint32_t at = queue_slot(i, n_front, P.n_paths);
             const NtF4 a_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od0[at])), b_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od1[at])),
@@ -693,6 +686,7 @@ struct rt_scene {
     int device = 0;
     uint32_t n_cu = 0;
     uint32_t n_leaves = 0;  // leaves of the tree (primitives that can be hit)
+    uint32_t n_long_leaves = 0;  // ... of which tested by the general primitive test (wrapped shapes, media)
     SceneView view{};
     std::vector<void*> allocs;
     hipStream_t own_stream = nullptr, side_stream[RT_MAX_PARTS - 1] = {};  // side streams: the other parts of a pass (see render_impl)
@@ -926,6 +920,12 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     {   // the walk's own node array (payload slots, leaf annotations, sentinel)
         std::vector<WalkNode> nodes;
         make_walk_nodes(D, nodes);
+        for (size_t pos = 0; pos + 1 < nodes.size();) {  // leaves whose test is the general one (see scan_queue_end); a leaf's skip link jumps over its payload slots
+            const WalkNode& N = nodes[pos];
+            if (N.prim < RT_NODE_LEAF) { ++pos; continue; }
+            if (!(N.prim & (RT_NODE_PLAIN_SPHERE | RT_NODE_PLAIN_BOX | RT_NODE_PLAIN_RECT))) ++sc->n_long_leaves;
+            pos = std::max<size_t>(N.skip / RT_NODE_STRIDE, pos + 1);
+        }
         if (nodes.size() * sizeof(WalkNode) >= RT_NODE_LEAF) {  // node positions are byte offsets and share a word with the leaf bits
             rt_scene_destroy(sc);
             return fail(RT_ERR_UNSUPPORTED, "BVH too large: node positions must stay below 2^28 bytes");
@@ -969,7 +969,8 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         const void* const walkers[] = {reinterpret_cast<const void*>(&k_tail<true, false>), reinterpret_cast<const void*>(&k_tail<true, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_WALK, false>), reinterpret_cast<const void*>(&k_shade<SHADE_WALK, true>),
-                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true>)};
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true>)};
         for (const void* f : walkers) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
     }
@@ -1247,7 +1248,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const bool sides = sc->view.side_rounding != 0u;  // (which build of the shading kernels: see stage_nodes)
     const auto tail_lds = sides ? &k_tail<true, true> : &k_tail<true, false>;
     const auto tail_global = sides ? &k_tail<false, true> : &k_tail<false, false>;
-    const auto shade_scan = sides ? &k_shade<SHADE_SCAN, true> : &k_shade<SHADE_SCAN, false>;
+    const auto shade_scan = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true> : &k_shade<SHADE_SCAN, false, true>)
+                                              : (sides ? &k_shade<SHADE_SCAN, true, false> : &k_shade<SHADE_SCAN, false, false>);
     const auto shade_walk = sides ? &k_shade<SHADE_WALK, true> : &k_shade<SHADE_WALK, false>;
     const auto shade_hits = sides ? &k_shade<SHADE_HITS, true> : &k_shade<SHADE_HITS, false>;
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
