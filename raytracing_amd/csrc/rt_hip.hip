@@ -103,6 +103,11 @@ __global__ void __launch_bounds__(RT_BS) k_raygen(PassParams P, RayQueue q, uint
     q.thr[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
 }
 
+// The queue lengths of a pass whose first bounce makes its own camera rays (k_shade<.., FIRST>): what k_raygen's first lane does.
+__global__ void __launch_bounds__(64) k_reset_counts(uint32_t* counts, uint32_t n_counts, uint32_t n_paths) {
+    for (uint32_t i = threadIdx.x; i < 2u * n_counts; i += 64u) counts[i] = i == 0 ? n_paths : 0u;
+}
+
 // A few rays of a queue, evenly spaced over it, for the host (see tune_tree): out[k] = {origin, direction} of entry
 // (k + 1/2) * count / n; a zero direction where the queue is empty.
 #define RT_TUNE_BOUNCES 16u      // bounces of the sampled pass that lend rays
@@ -376,6 +381,9 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 #ifndef RT_SHADE_PRIO
 #define RT_SHADE_PRIO 3
 #endif
+#ifndef RT_SCAN_FIRST
+#define RT_SCAN_FIRST 1
+#endif
 #define RT_SCAN_MAX_LEAVES 16u   // leaves up to which a bounce runs as one kernel that scans them
 // How k_shade gets a ray's closest hit:
 //   SHADE_HITS  from the hit records of a k_traverse launch;
@@ -447,7 +455,7 @@ __device__ __forceinline__ bool scan_queue_end(const SceneView& S, const Ray& r)
 #define RT_SCAN_GRID_PER_CU 8u  // workgroups of a scanned bounce per CU (four are resident at a time)
 #endif
 __host__ __device__ constexpr uint32_t shade_bs(int mode) { return mode == 2 /* SHADE_SCAN */ ? 256u : RT_SHADE_BS; }
-template <int MODE, bool SIDES, bool LONG_LEAVES = false>
+template <int MODE, bool SIDES, bool LONG_LEAVES = false, bool FIRST = false>
 __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
     constexpr uint32_t BS = shade_bs(MODE);
@@ -461,7 +469,9 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_
     // changed nothing).  On its own the kernel is a few per cent slower with the priority raised, so it is only raised there.
     if (MODE == SHADE_HITS && P.overlapped) __builtin_amdgcn_s_setprio(RT_SHADE_PRIO);
     const SceneView S = stage_nodes<MODE != SHADE_HITS, SIDES>(S0, lds_nodes);
-    const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
+    // FIRST (scanned scenes): bounce 0 makes its camera rays itself instead of reading them from a queue that k_raygen has
+    // written (96 bytes per path less through memory; perlin's paths are 2.3 segments long)
+    const uint32_t n_front = FIRST ? P.n_paths : count_ptr[0], count = FIRST ? P.n_paths : n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t base = blockIdx.x * BS; base < count; base += gridDim.x * BS) {
         const uint32_t i = base + threadIdx.x;
@@ -472,7 +482,14 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_
             DrawKey key = make_key(P, 0u, 0u, bounce);
             r.o = v3(0.0f, 0.0f, 0.0f); r.d = v3(1.0f, 1.0f, 1.0f); r.time = 0.0f; thr = v3(0.0f, 0.0f, 0.0f);
             const bool live = i < count;
-            if (live) {
+            if (live && FIRST) {  // (as k_raygen)
+                path = i;
+                const uint32_t sample = path_sample(P, path);
+                pixel = P.owned[path - (sample - P.sample_base) * P.n_owned];
+                r = camera_ray(P.cam, pixel % P.width, pixel / P.width, P.width, P.height, sample, P.k0, P.k1);
+                thr = v3(1.0f, 1.0f, 1.0f);
+                key = make_key(P, path, pixel, bounce);
+            } else if (live) {
                 const uint32_t at = queue_slot(i, n_front, P.n_paths);
                 const NtF4 a = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od0[at])), b = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od1[at])),
                            c = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.thr[at]));
@@ -970,7 +987,9 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
         const void* const walkers[] = {reinterpret_cast<const void*>(&k_tail<true, false>), reinterpret_cast<const void*>(&k_tail<true, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_WALK, false>), reinterpret_cast<const void*>(&k_shade<SHADE_WALK, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true>),
-                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true>)};
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, false, true>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, true>)};
         for (const void* f : walkers) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
     }
@@ -1250,6 +1269,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const auto tail_global = sides ? &k_tail<false, true> : &k_tail<false, false>;
     const auto shade_scan = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true> : &k_shade<SHADE_SCAN, false, true>)
                                               : (sides ? &k_shade<SHADE_SCAN, true, false> : &k_shade<SHADE_SCAN, false, false>);
+    const auto shade_scan_first = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true, true> : &k_shade<SHADE_SCAN, false, true, true>)
+                                                    : (sides ? &k_shade<SHADE_SCAN, true, false, true> : &k_shade<SHADE_SCAN, false, false, true>);
     const auto shade_walk = sides ? &k_shade<SHADE_WALK, true> : &k_shade<SHADE_WALK, false>;
     const auto shade_hits = sides ? &k_shade<SHADE_HITS, true> : &k_shade<SHADE_HITS, false>;
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
@@ -1272,6 +1293,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         // Queue lengths are read back (one sync per bounce) only while the hand-over point to k_tail is
         // still unknown, when profiling, or when k_tail is disabled; otherwise nothing waits on the host.
         const bool readback = !fixed && (tail_from < 0 || profile || force_wavefront);
+        // a scanned scene's first bounce makes its own camera rays (unless the pass goes to k_tail at once)
+        const bool first_is_scan = RT_SCAN_FIRST && fused && scan && !(tail_from == 0 && !force_wavefront);
         const bool calibrating = !fixed && tail_from < 0 && !profile;  // this pass also times its kernels, to see whether splitting later passes pays
         L.profile = profile || calibrating;
         const int n_halves = (!fixed && !readback && split_pays && ns >= RT_PASS_PARTS && !(ro->flags & RT_RENDER_ONE_STREAM)) ? RT_PASS_PARTS : 1;
@@ -1300,7 +1323,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             scan_grid[k] = std::min((h.P.n_paths + shade_bs(SHADE_SCAN) - 1) / shade_bs(SHADE_SCAN), sc->n_cu * RT_SCAN_GRID_PER_CU);
             trav_grid[k] = std::min((h.P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, sc->n_cu);
             if (k == 0 && (st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
-            hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, h.stream, h.P, h.q[0], h.counts, n_counts);
+            if (first_is_scan) hipLaunchKernelGGL(k_reset_counts, dim3(1), dim3(64), 0, h.stream, h.counts, n_counts, h.P.n_paths);
+            else hipLaunchKernelGGL(k_raygen, dim3(grid_full), dim3(RT_BS), 0, h.stream, h.P, h.q[0], h.counts, n_counts);
             if (k == 0 && (st = L.end(ev)) != RT_OK) return st;
             sc->prof.samples += h.P.n_paths;
         }
@@ -1327,7 +1351,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 }
                 if (n_halves == 1 && (st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
                 if (fused && scan)
-                    hipLaunchKernelGGL(shade_scan, dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes, h.stream, sc->view, h.P,
+                    hipLaunchKernelGGL(b == 0 && first_is_scan ? shade_scan_first : shade_scan, dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes, h.stream, sc->view, h.P,
                                        h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + 1, h.values, b);
                 else if (fused)
                     hipLaunchKernelGGL(shade_walk, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P,
