@@ -13,7 +13,8 @@ frame's schedule).
 Rank 0 prints one JSON line.  `roofline` prices the kernel that takes most of the frame.  For the BVH traversal that is
 the fp32 vector peak: algorithmic flops per path segment are counted by the CPU oracle on the reference's traversal order
 (per-operation constants below).  For shading it is the HBM peak: 56 bytes read per segment (ray, throughput, hit record)
-and 48 written when the path goes on or 16 when it ends.  Either is divided by the kernel's average launch duration,
+and 48 written when the path goes on or 16 when it ends (scenes whose bounce is one kernel: no hit record, and no read in
+a path's first segment, whose camera ray the kernel makes itself).  Either is divided by the kernel's average launch duration,
 measured here with HIP events in a profiled render after the timed one (kernels one after the other on one stream, which is
 the duration a kernel trace of `bench.py --one-stream` shows; the timed render overlaps the traversal of one half of a pass
 with the shading of the other half on two streams where that pays).  `roofline.counters` are the rocprofv3 PMC figures of
@@ -197,7 +198,9 @@ def main():
                 # every path ends exactly once, all but a sliver of them in a shading launch: dead = paths, alive = segments - paths
                 paths, segs = prof["samples"], prof["traverse_segments"]
                 seg_per_launch = segs / max(prof["shade_launches"], 1)
-                bytes_per_seg = SHADE_BYTES_IN - (8 if fused else 0) + (SHADE_BYTES_OUT_ALIVE * max(segs - paths, 0) + SHADE_BYTES_OUT_DEAD * min(paths, segs)) / max(segs, 1)
+                # (one kernel per bounce: no hit record, and the first bounce makes its own camera rays instead of reading them)
+                bytes_in = (SHADE_BYTES_IN - 8) * max(segs - paths, 0) / max(segs, 1) if fused else SHADE_BYTES_IN
+                bytes_per_seg = bytes_in + (SHADE_BYTES_OUT_ALIVE * max(segs - paths, 0) + SHADE_BYTES_OUT_DEAD * min(paths, segs)) / max(segs, 1)
                 ms_per_launch = prof["shade_ms"] / max(prof["shade_launches"], 1)
                 achieved = bytes_per_seg * seg_per_launch / (ms_per_launch * 1e-3) / 1e9
                 pmc = pmc_counters(args.config, "k_shade")

@@ -1,6 +1,6 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-T=r02i
+T=r02j
 for cfg in final_scene cornell perlin cornell_smoke; do
   timeout -k 10 400 python bench.py --config $cfg --steps $([ $cfg = final_scene ] && echo 1 || echo 3) > gpurun_out/${T}_bench_$cfg.json.log 2> gpurun_out/${T}_bench_$cfg.err || exit 1
 done

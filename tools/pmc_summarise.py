@@ -84,7 +84,12 @@ def main(root, out_json, out_md):
         for k in ("k_traverse", "k_shade"):
             if k not in sq:
                 continue
-            algo_k = 95 if (fused and k == "k_shade") else algo[k]
+            if fused and k == "k_shade":
+                # ray in (48 B; the first bounce makes its own camera rays) and ray out (48 B) for every segment but a path's last, which writes the sample's value (16 B)
+                paths = work["width"] * work["height"] * work["spp"]
+                algo_k = round((96.0 * max(seg - paths, 0) + 16.0 * min(paths, seg)) / seg, 1)
+            else:
+                algo_k = algo[k]
             s = sq[k]
             launches, ns = dur.get(k, [0, 0.0])
             hbm = (2.0 * fe[k].get("FETCH_SIZE", 0.0) + wr[k].get("WRITE_SIZE", 0.0)) * 1024.0
