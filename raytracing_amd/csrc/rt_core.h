@@ -1345,10 +1345,12 @@ RT_HD Ray camera_ray(const rt_camera& C, uint32_t i, uint32_t j, uint32_t width,
     double dx, dy;
     for (uint32_t round = 1;; ++round) {  // InsideUnitDisc (geometry.rs:397-408), two candidates per Philox block
         const U4 q = philox4x32_10(pixel, sample, RT_TAG_CAMERA, round, k0, k1);
+        // (norm >= 1 decided on the squared norm: the candidates are odd multiples of 2^-23, so their squares and the sum
+        // are exact multiples of 2^-46, and such a sum is below 1 iff its correctly rounded square root is)
         dx = -1.0 + 2.0 * (double)u01(q.x); dy = -1.0 + 2.0 * (double)u01(q.y);
-        if (!(sqrt(dx * dx + dy * dy) >= 1.0)) break;
+        if (!(dx * dx + dy * dy >= 1.0)) break;
         dx = -1.0 + 2.0 * (double)u01(q.z); dy = -1.0 + 2.0 * (double)u01(q.w);
-        if (!(sqrt(dx * dx + dy * dy) >= 1.0)) break;
+        if (!(dx * dx + dy * dy >= 1.0)) break;
     }
     dx *= C.lens_radius; dy *= C.lens_radius;
     D3 offset = d3(C.u) * dx + d3(C.v) * dy;
