@@ -336,7 +336,9 @@ def test_image_parity(name, spp, earth):
 
 
 def test_result_does_not_depend_on_passes_kernel_split_or_ranks(earth):
-    for name, spp, w, h in [("cornell_smoke", 24, 70, 50), ("final_scene", 12, 64, 64), ("random_spheres", 16, 80, 45)]:
+    # (cornell, cornell_smoke and perlin between them run every build of the one-kernel bounce: with and without side rounding,
+    # with and without the queue key by long-test leaves, and the first bounce that makes its own camera rays)
+    for name, spp, w, h in [("cornell_smoke", 24, 70, 50), ("final_scene", 12, 64, 64), ("random_spheres", 16, 80, 45), ("cornell", 16, 48, 48), ("perlin", 16, 64, 36)]:
         sc, co = _example(name, earth)
         cam = rt.Camera(co)
         io = rt.ImageOptions(h, w, spp, 50)
