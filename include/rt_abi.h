@@ -12,8 +12,13 @@
  *   - every function returns an rt_status and never aborts across the ABI;
  *     rt_last_error() returns a thread-local message for the last failure;
  *   - "device" pointers are HIP device addresses on the scene's device;
- *   - a scene handle is immutable after creation; rendering calls that share a
- *     handle must not overlap (they share the handle's device workspace).
+ *   - a scene handle owns device state that rendering changes (a workspace that
+ *     grows with the frame, streams, the schedule learnt from earlier frames, the
+ *     regrouped tree): every entry point that takes a handle holds the handle's
+ *     lock for the duration of the call, so calls from several threads on one
+ *     handle are safe and run one after the other.  rt_render_device returns with
+ *     its work still queued; the next call on the handle queues behind it.
+ *     rt_scene_destroy must not run beside any other call on the handle.
  */
 #ifndef RT_ABI_H
 #define RT_ABI_H
@@ -25,7 +30,10 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u
+/* 3: rt_profile grew (tail_from, two_stream_passes, pass_paths); rt_render_options.stream orders the render with the caller's
+ * stream instead of naming the launch stream; noise textures read rt_texture.odd / even / color; new RT_RENDER_* and RT_PRIM_*
+ * bits.  rt_scene_create refuses a description that carries another version. */
+#define RT_ABI_VERSION 3u
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -338,6 +346,12 @@ typedef struct rt_profile {
      * they are: inner nodes only cull).  These two say what that did, per sampled ray, since the handle was made: box tests
      * with the tree grouped by box areas and with the tree in use now (equal, or both 0, while nothing has been regrouped). */
     double tree_tests_by_area, tree_tests_sampled;
+    /* The schedule of the last pass of the last render call (set by every call, profiled or not): the bounce from which the
+     * tail kernel ran every remaining segment (max_reflections if it never did), how many passes of the call ran as two
+     * halves on two streams, and the number of paths of a full pass.  The schedule is learnt per (frame shape, pass size). */
+    int32_t tail_from;
+    uint32_t two_stream_passes;
+    uint64_t pass_paths;
 } rt_profile;
 rt_status rt_get_profile(rt_scene* scene, rt_profile* out);
 

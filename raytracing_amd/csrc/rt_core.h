@@ -1398,5 +1398,41 @@ RT_HD uint8_t quantise(double x) {
     return (uint8_t)y;
 }
 
+// ----------------------------------------------------------- tile ownership
+// The frame is cut into tiles of tw x th pixels, numbered tile_id = ty * ntx + tx over (column, row counted from the bottom);
+// rank `rank` of `world` renders the tiles with tile_id % world == rank.  Edge tiles are cut off at the frame's border.
+struct TileGrid {
+    uint32_t W, H, tw, th, rank, world;
+    RT_HD uint32_t ntx() const { return (W + tw - 1) / tw; }
+    RT_HD uint32_t nty() const { return (H + th - 1) / th; }
+    RT_HD uint64_t ntiles() const { return (uint64_t)ntx() * nty(); }
+};
+// Numbers t in [0, x) with t % m == r.
+RT_HD uint64_t count_residue_below(uint64_t x, uint32_t r, uint32_t m) { return x > r ? (x - r - 1) / m + 1 : 0; }
+// Whether the last tile of tile row `ty` belongs to the rank and has a number below t_end (the one term of the count below
+// that has no closed form: callers sum it over the tile rows, the device spread over a workgroup's threads).
+RT_HD uint32_t owned_last_column_tile(const TileGrid& G, uint32_t ty, uint64_t t_end) {
+    const uint64_t t = (uint64_t)ty * G.ntx() + G.ntx() - 1;
+    return (t < t_end && t % G.world == G.rank) ? 1u : 0u;
+}
+// Pixels in the rank's tiles with a number below t_end (t_end = ntiles(): all of the rank's pixels), given
+// last_column = the sum of owned_last_column_tile over all tile rows.  Every owned tile counts tw * th, less the cut of the
+// last column and of the last row.
+RT_HD uint64_t owned_pixels_below(const TileGrid& G, uint64_t t_end, uint64_t last_column) {
+    const uint64_t ntx = G.ntx(), nty = G.nty(), n = ntx * nty;
+    if (t_end > n) t_end = n;
+    const uint64_t dw = ntx * G.tw - G.W, dh = nty * G.th - G.H;  // what the last column / row lack of a full tile
+    const uint64_t all = count_residue_below(t_end, G.rank, G.world);
+    const uint64_t row0 = (nty - 1) * ntx;  // first tile of the last row
+    const uint64_t last_row = count_residue_below(t_end, G.rank, G.world) - count_residue_below(row0 < t_end ? row0 : t_end, G.rank, G.world);
+    const uint64_t corner = (n - 1 < t_end && (n - 1) % G.world == G.rank) ? 1 : 0;
+    return all * G.tw * G.th - last_column * dw * G.th - last_row * G.tw * dh + corner * dw * dh;
+}
+inline uint64_t owned_pixels_below(const TileGrid& G, uint64_t t_end) {  // (host side)
+    uint64_t last_column = 0;
+    for (uint32_t ty = 0; ty < G.nty(); ++ty) last_column += owned_last_column_tile(G, ty, t_end);
+    return owned_pixels_below(G, t_end, last_column);
+}
+
 }  // namespace rt
 #endif

@@ -125,38 +125,30 @@ __global__ void __launch_bounds__(64) k_sample_rays(RayQueue q, const uint32_t* 
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y;
 }
 
-// The pixels this rank owns, tile by tile (tile_id = ty * ntx + tx, owner = tile_id % world_size), rows of a tile bottom-up
-// and left to right: owned[k] = j * width + i.  One workgroup: every thread takes a tile, a scan over the tiles' pixel
-// counts gives each its place in the list.  (The order of the list only lays out the workspace; every draw is keyed by
-// the pixel's number in the frame.)
-__global__ void __launch_bounds__(1024) k_owned_list(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world, uint32_t* owned) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t running;
-    const uint32_t ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th, ntiles = ntx * nty, tid = threadIdx.x;
-    if (tid == 0) running = 0;
+// The pixels this rank owns, tile by tile (TileGrid in rt_core.h), rows of a tile bottom-up and left to right:
+// owned[k] = j * width + i.  Workgroup (x, y) writes rows [y * rows_per_block, (y + 1) * rows_per_block) of the rank's x-th
+// tile; the tile's place in the list is the number of pixels in the rank's earlier tiles (owned_pixels_below: closed form
+// but for one sum over the tile rows, which the workgroup's threads share).  (The order of the list only lays out the
+// workspace; every draw is keyed by the pixel's number in the frame.)
+#define RT_OWNED_BS 256
+__global__ void __launch_bounds__(RT_OWNED_BS) k_owned_list(TileGrid G, uint32_t rows_per_block, uint32_t* owned) {
+    __shared__ uint32_t last_column;
+    const uint64_t tile = (uint64_t)G.rank + (uint64_t)blockIdx.x * G.world;
+    if (threadIdx.x == 0) last_column = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < ntiles; base += 1024u) {
-        const uint32_t tile = base + tid;
-        uint32_t cnt = 0, x0 = 0, y0 = 0, cw = 0, ch = 0;
-        if (tile < ntiles && tile % world == rank) {
-            x0 = (tile % ntx) * tw; y0 = (tile / ntx) * th;
-            cw = min(tw, W - x0); ch = min(th, H - y0);
-            cnt = cw * ch;
-        }
-        part[tid] = cnt;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024u; off <<= 1) {  // inclusive scan
-            const uint32_t v = tid >= off ? part[tid - off] : 0u;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        uint32_t at = running + part[tid] - cnt;
-        for (uint32_t y = 0; y < ch; ++y)
-            for (uint32_t x = 0; x < cw; ++x) owned[at++] = (y0 + y) * W + x0 + x;
-        __syncthreads();
-        if (tid == 1023u) running += part[1023];
-        __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t ty = threadIdx.x; ty < G.nty(); ty += RT_OWNED_BS) mine += owned_last_column_tile(G, ty, tile);
+    if (mine) atomicAdd(&last_column, mine);
+    __syncthreads();
+    const uint64_t base = owned_pixels_below(G, tile, last_column);
+    const uint32_t x0 = (uint32_t)(tile % G.ntx()) * G.tw, y0 = (uint32_t)(tile / G.ntx()) * G.th;
+    const uint32_t cw = min(G.tw, G.W - x0), ch = min(G.th, G.H - y0);
+    const uint32_t r0 = blockIdx.y * rows_per_block;
+    if (r0 >= ch) return;
+    const uint32_t rows = min(rows_per_block, ch - r0);
+    for (uint64_t k = threadIdx.x; k < (uint64_t)rows * cw; k += RT_OWNED_BS) {
+        const uint32_t y = r0 + (uint32_t)(k / cw), x = (uint32_t)(k % cw);
+        owned[base + (uint64_t)y * cw + x] = (y0 + y) * G.W + x0 + x;
     }
 }
 
@@ -697,9 +689,12 @@ struct Workspace {
 };
 // What the first pass of a frame learns by reading queue lengths back and timing its kernels, kept per frame shape so
 // that repeat frames (and every frame of a rank with a small share) run without a host round trip.  It only schedules:
-// the image does not depend on it.
-struct Calibration { uint32_t width, height, depth, n_owned; int tail_from; bool split_pays; };
+// the image does not depend on it.  The bounce at which the queue is short enough for the tail kernel is learnt against an
+// absolute length, so it belongs to the pass size it was seen at (`pass_paths`: a frame of one sample per pixel hands over
+// after a bounce, the same frame in passes of 64 M paths after ten), and so does the comparison of the two kernels' times.
+struct Calibration { uint32_t width, height, depth, n_owned; uint64_t pass_paths; int tail_from; bool split_pays; };
 struct rt_scene {
+    std::mutex mutex;  // held by every entry point for the duration of a call: rendering changes the handle (workspace, schedule, tree, profile)
     int device = 0;
     uint32_t n_cu = 0;
     uint32_t n_leaves = 0;  // leaves of the tree (primitives that can be hit)
@@ -1090,18 +1085,6 @@ static rt_status validate_render(rt_scene* sc, const rt_camera* cam, const rt_im
     return RT_OK;
 }
 
-// Number of pixels in the tiles rank `rank` owns (tile_id % world_size == rank), without listing them.
-static uint64_t count_owned(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world) {
-    const uint32_t ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th;
-    uint64_t n = 0;
-    for (uint32_t ty = 0; ty < nty; ++ty) {
-        const uint64_t ch = std::min(th, H - ty * th);
-        for (uint32_t tx = 0; tx < ntx; ++tx)
-            if ((ty * ntx + tx) % world == rank) n += ch * std::min(tw, W - tx * tw);
-    }
-    return n;
-}
-
 // Renders this rank's pixels into d_mean_out (full frame of doubles on the device).
 // `fixed`: the workspace of the variant that allocates nothing (null: the scene handle's own, grown as needed).  That
 // variant also creates no events and reads nothing back: it hands over to k_tail at a bounce fixed in advance.
@@ -1183,12 +1166,13 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const bool profile = (ro->flags & RT_RENDER_PROFILE) != 0;
     if (fixed && profile) return fail(RT_ERR_INVALID_ARGUMENT, "RT_RENDER_PROFILE creates events: not available without allocation");
     const uint32_t W = io->width, H = io->height;
-    const uint32_t tw = ro->tile_w ? ro->tile_w : 16, th = ro->tile_h ? ro->tile_h : 16;
-    if ((uint64_t)((W + tw - 1) / tw) * ((H + th - 1) / th) >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many tiles");
+    // (a tile larger than the frame is the frame)
+    const TileGrid tiles{W, H, std::min(ro->tile_w ? ro->tile_w : 16u, W), std::min(ro->tile_h ? ro->tile_h : 16u, H), ro->rank, ro->world_size};
+    if (tiles.ntiles() >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "too many tiles");
     const uint64_t spp = io->samples_per_pixel;
     const uint32_t depth = (uint32_t)io->max_reflections;
     const uint32_t n_counts = depth + 2;
-    const uint64_t n_owned64 = count_owned(W, H, tw, th, ro->rank, ro->world_size);
+    const uint64_t n_owned64 = owned_pixels_below(tiles, tiles.ntiles());
     if (fixed && (n_owned64 > fixed->pixels || n_counts > fixed->n_counts)) {
         char msg[200];
         snprintf(msg, sizeof(msg), "the fixed workspace holds at most %llu pixels per rank and max_reflections %u (this frame: %llu pixels, %u)",
@@ -1219,7 +1203,12 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         S = (S + 1) / 2;
     }
     const Workspace& ws = fixed ? *fixed : sc->ws;
-    hipLaunchKernelGGL(k_owned_list, dim3(1), dim3(1024), 0, stream, W, H, tw, th, ro->rank, ro->world_size, ws.owned);
+    sc->prof.pass_paths = S * n_owned;
+    {   // (n_owned != 0: the rank has at least one tile)
+        const uint32_t my_tiles = (uint32_t)count_residue_below(tiles.ntiles(), tiles.rank, tiles.world);
+        const uint32_t rows_per_block = std::max(16u, (tiles.th + 65534u) / 65535u);
+        hipLaunchKernelGGL(k_owned_list, dim3(my_tiles, (tiles.th + rows_per_block - 1) / rows_per_block), dim3(RT_OWNED_BS), 0, stream, tiles, rows_per_block, ws.owned);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(ws.accum, 0, (size_t)n_owned * 3 * sizeof(double), stream));
 
@@ -1248,7 +1237,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     bool split_pays = false;               // set by the calibrating pass: traversal dominates shading
     Calibration* known = nullptr;
     for (auto& c : sc->calibrations)
-        if (c.width == W && c.height == H && c.depth == depth && c.n_owned == n_owned) known = &c;
+        if (c.width == W && c.height == H && c.depth == depth && c.n_owned == n_owned && c.pass_paths == S * n_owned) known = &c;
     if (fixed && tail_from < 0 && !force_wavefront) {
         // nothing is read back: queues of a pass this small are short after a bounce or two
         tail_from = S * n_owned > tail_threshold ? (int)std::min<uint32_t>(depth, 2u) : 0;
@@ -1329,6 +1318,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             sc->prof.samples += h.P.n_paths;
         }
         sc->prof.passes += 1;
+        sc->prof.two_stream_passes += n_halves > 1 ? 1u : 0u;
         // The first sizeable pass on a scene handle lends some of its rays to the regrouping of the tree (tune_tree).
         const bool sampling = !fixed && !sc->tree_tuned && !(ro->flags & RT_RENDER_KEEP_TREE) && !fused && sc->n_leaves > RT_SCAN_MAX_LEAVES &&
                               half[0].P.n_paths >= RT_TUNE_MIN_PATHS;
@@ -1374,6 +1364,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             }
         }
         if (tail_from < 0 && !force_wavefront) tail_from = (int)depth;
+        sc->prof.tail_from = tail_from >= 0 ? tail_from : (int32_t)depth;
         if (!finished && b < depth) {
             for (int k = 0; k < n_halves; ++k) {
                 if (n_halves == 1 && (st = L.begin(RT_K_TAIL, &ev)) != RT_OK) return st;
@@ -1405,7 +1396,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             split_pays = fused || sc->prof.kernel_ms[RT_K_TRAVERSE] - keep.kernel_ms[RT_K_TRAVERSE] > 1.5 * (sc->prof.kernel_ms[RT_K_SHADE] - keep.kernel_ms[RT_K_SHADE]);
             sc->prof = keep;
             if (!force_wavefront && !force_tail && ns == S) {  // (a full-size pass: what it saw holds for the passes to come)
-                const Calibration c{W, H, depth, n_owned, tail_from, split_pays};
+                const Calibration c{W, H, depth, n_owned, S * n_owned, tail_from, split_pays};
                 if (known) *known = c;
                 else { if (sc->calibrations.size() >= 64) sc->calibrations.erase(sc->calibrations.begin()); sc->calibrations.push_back(c); known = &sc->calibrations.back(); }
             }
@@ -1428,9 +1419,13 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     return hand_back();
 }
 
+static rt_status quantise_impl(rt_scene* sc, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream);
+
 extern "C" {
 
 rt_status rt_render_device(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, double* d_mean_out) {
+    if (!sc) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(sc->mutex);
     return render_impl(sc, cam, io, ro, d_mean_out, false, nullptr);
 }
 
@@ -1438,12 +1433,18 @@ rt_status rt_render_device_noalloc(rt_scene* sc, const rt_camera* cam, const rt_
     if (!sc) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     unsigned char* base = (sc->device >= 0 && sc->device < RT_MAX_DEVICES) ? g_scratch_ptr[sc->device] : nullptr;
     if (!base) return fail(RT_ERR_UNSUPPORTED, "this device has no static workspace (device index beyond the library's table)");
+    std::lock_guard<std::mutex> lock(sc->mutex);
     const Workspace ws = static_workspace(base);
     return render_impl(sc, cam, io, ro, d_mean_out, false, &ws);
 }
 
 rt_status rt_quantise_device(rt_scene* sc, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream) {
     if (!sc || !d_mean || !d_rgb_out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(sc->mutex);
+    return quantise_impl(sc, d_mean, n, d_rgb_out, stream);
+}
+}  // extern "C"
+static rt_status quantise_impl(rt_scene* sc, const double* d_mean, uint64_t n, uint8_t* d_rgb_out, void* stream) {
     HIP_TRY(hipSetDevice(sc->device));
     hipStream_t s = stream ? (hipStream_t)stream : sc->own_stream;
     if (n == 0) return RT_OK;
@@ -1451,11 +1452,13 @@ rt_status rt_quantise_device(rt_scene* sc, const double* d_mean, uint64_t n, uin
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
+extern "C" {
 
 rt_status rt_render(rt_scene* sc, const rt_camera* cam, const rt_image_options* io, const rt_render_options* ro, uint8_t* rgb_out, double* mean_out) {
     rt_status st = validate_render(sc, cam, io, ro);
     if (st != RT_OK) return st;
     if (!rgb_out && !mean_out) return fail(RT_ERR_INVALID_ARGUMENT, "no output buffer");
+    std::lock_guard<std::mutex> lock(sc->mutex);
     HIP_TRY(hipSetDevice(sc->device));
     const size_t n = (size_t)3 * io->width * io->height;
     double* d_mean = nullptr; uint8_t* d_rgb = nullptr;
@@ -1465,7 +1468,7 @@ rt_status rt_render(rt_scene* sc, const rt_camera* cam, const rt_image_options* 
     if (st == RT_OK && rgb_out) {
         hipError_t e = hipMalloc((void**)&d_rgb, n);
         if (e != hipSuccess) st = fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc(rgb)");
-        if (st == RT_OK) st = rt_quantise_device(sc, d_mean, n, d_rgb, stream);
+        if (st == RT_OK) st = quantise_impl(sc, d_mean, n, d_rgb, stream);
         if (st == RT_OK && hipMemcpyAsync(rgb_out, d_rgb, n, hipMemcpyDeviceToHost, stream) != hipSuccess) st = fail(RT_ERR_HIP, "copy of the image to the host failed");
     }
     if (st == RT_OK && mean_out && hipMemcpyAsync(mean_out, d_mean, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess)
@@ -1490,6 +1493,7 @@ rt_status rt_debug_trav_stats(unsigned long long* out16) {
 
 rt_status rt_get_profile(rt_scene* sc, rt_profile* out) {
     if (!sc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(sc->mutex);
     *out = sc->prof;
     out->tree_tests_by_area = sc->tree_tests_by_area; out->tree_tests_sampled = sc->tree_tests_sampled;  // (of the handle, not of the last call)
     return RT_OK;
@@ -1500,6 +1504,7 @@ rt_status rt_intersect_batch(rt_scene* sc, int64_t scope, const rt_ray* rays, ui
     if (scope >= (int64_t)sc->view.n_prims) return fail(RT_ERR_INVALID_ARGUMENT, "scope is not a primitive of this scene");
     if (n == 0) return RT_OK;
     if (n >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "batch too large");
+    std::lock_guard<std::mutex> lock(sc->mutex);
     HIP_TRY(hipSetDevice(sc->device));
     rt_ray* d_rays = nullptr; rt_hit* d_out = nullptr; float* d_mu = nullptr;
     rt_status st = RT_OK;
@@ -1524,6 +1529,7 @@ rt_status rt_scatter_batch(rt_scene* sc, const rt_hit* hits, uint64_t n, uint64_
     if (n >= (1ull << 31)) return fail(RT_ERR_UNSUPPORTED, "batch too large");
     for (uint64_t i = 0; i < n; ++i)
         if (hits[i].prim >= sc->view.n_prims) return fail(RT_ERR_INVALID_ARGUMENT, "hit record names a primitive this scene does not have");
+    std::lock_guard<std::mutex> lock(sc->mutex);
     HIP_TRY(hipSetDevice(sc->device));
     rt_hit* d_hits = nullptr; rt_scatter* d_out = nullptr; uint32_t* d_keys = nullptr;
     auto cleanup = [&]() { if (d_hits) (void)hipFree(d_hits); if (d_out) (void)hipFree(d_out); if (d_keys) (void)hipFree(d_keys); };
@@ -1547,6 +1553,7 @@ rt_status rt_camera_rays(rt_scene* sc, const rt_camera* cam, const rt_image_opti
     if (n == 0) return RT_OK;
     for (uint64_t k = 0; k < n; ++k)
         if (px_i[k] >= io->width || px_j[k] >= io->height) return fail(RT_ERR_INVALID_ARGUMENT, "pixel out of range");
+    std::lock_guard<std::mutex> lock(sc->mutex);
     HIP_TRY(hipSetDevice(sc->device));
     uint32_t* d_idx = nullptr; rt_ray* d_out = nullptr;
     auto cleanup = [&]() { if (d_idx) (void)hipFree(d_idx); if (d_out) (void)hipFree(d_out); };

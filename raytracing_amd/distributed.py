@@ -14,6 +14,8 @@ stream IS 0.  The render and the quantisation therefore run on a torch side stre
 that the collective (ordered after the current stream) reads a finished frame and the caller only
 ever has to synchronise the current stream.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -44,11 +46,12 @@ def owned_mask(width, height, rank, world_size, tile_w=TILE_W, tile_h=TILE_H):
 
 
 def gather_frames(local_mean: torch.Tensor, dst: int = 0, group=None) -> torch.Tensor:
-    """Sum-reduce of the per-rank frames (zeros outside the owned tiles) to `dst`; in place."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if local_mean.is_cuda and dist.get_backend(group) == "gloo":
-            # rehearsals only (several ranks on one GPU, no RCCL): through the host -- gloo's own handling of device tensors
-            # hung on the second collective of a process on this ROCm build
+    """Sum-reduce of the per-rank frames (zeros outside the owned tiles) to `dst`; in place.  Runs whenever a process group
+    exists, a group of one included (the collective is then the identity, and a one-GPU box can exercise the RCCL call)."""
+    if dist.is_available() and dist.is_initialized():
+        if local_mean.is_cuda and dist.get_backend(group) == "gloo" and not os.environ.get("RT_GLOO_DEVICE_TENSORS"):
+            # rehearsals only (several ranks on one GPU, no RCCL): the frame goes through the host here, and gloo sums host
+            # tensors.  (Handed the device tensor, gloo stages it through pinned memory on streams of its own.)
             host = local_mean.cpu()
             dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
             if dist.get_rank(group) == dst:

@@ -3,7 +3,7 @@
 #![allow(dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const RT_ABI_VERSION: u32 = 2;
+pub const RT_ABI_VERSION: u32 = 3;
 
 pub const RT_GEOM_SPHERE: u8 = 0;
 pub const RT_GEOM_MOVING_SPHERE: u8 = 1;

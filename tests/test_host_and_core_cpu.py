@@ -32,7 +32,7 @@ def test_abi_header_symbols_are_exported():
     lib = _abi.hip_lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rt_abi_version() == 2
+    assert lib.rt_abi_version() == 3
     _abi.host_lib()
 
 

@@ -241,6 +241,11 @@ void twin_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) {
     U4 r = philox4x32_10(c[0], c[1], c[2], c[3], k[0], k[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }
 uint8_t twin_quantise(double x) { return quantise(x); }
+// Pixels in the tiles of `rank` with a tile number below t_end (the place of tile t_end in the rank's pixel list).
+uint64_t twin_owned_pixels_below(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t rank, uint32_t world, uint64_t t_end) {
+    const TileGrid G{W, H, tw < W ? tw : W, th < H ? th : H, rank, world};
+    return owned_pixels_below(G, t_end);
+}
 
 // The whole per-pixel loop (raygen -> closest_hit / shade_step per bounce -> f64 sum in sample order),
 // i.e. what the kernels compute, on host threads.  mean_out: 3*w*h doubles, top row first.
