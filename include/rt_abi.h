@@ -238,7 +238,9 @@ typedef struct rt_render_options {
                                  on the library's own streams).  NULL = no ordering with any caller stream: the render runs on
                                  the library's own (non-blocking) streams alone, the null stream included in "no ordering";
                                  a caller that works on the legacy default stream, whose handle is also 0, passes a stream of
-                                 its own and orders the two with events */
+                                 its own and orders the two with events.  The stream must have default priority (RT_ERR_UNSUPPORTED
+                                 otherwise): a stream of raised priority that waits for the library's streams is never released
+                                 on this runtime */
 } rt_render_options;
 enum {
     RT_RENDER_PROFILE = 1u,  /* time every kernel launch with HIP events (rt_get_profile) */
@@ -282,9 +284,14 @@ rt_status rt_render_device(rt_scene* scene, const rt_camera* camera, const rt_im
  * static device array of the library's image (about 38.5 MB on every GPU the library is loaded on, held until the
  * process ends).  Limits, checked up front (RT_ERR_UNSUPPORTED beyond them): at most 262 144 pixels owned by this rank
  * (512 x 512 on one rank) and max_reflections <= 254; passes hold at most 262 144 paths.  RT_RENDER_PROFILE is refused.
- * All calls on one GPU share that GPU's array, whichever scene handle they use: calls that overlap on a GPU race (every
- * call overwrites what it reads before reading it, so nothing needs clearing between calls).  Returns after the work is
- * enqueued on the stream; the caller synchronises. */
+ * All calls on one GPU share that GPU's array, whichever scene handle they use: calls whose device work overlaps on a GPU
+ * race (every call overwrites what it reads before reading it, so nothing needs clearing between calls).  Calls on one
+ * handle queue one behind the other on the handle's stream.  Calls on different handles run on different streams: the
+ * caller orders them by giving both the same `stream` (the second call then starts after the first has handed that
+ * stream back) or by synchronising in between; with stream = NULL nothing orders them.
+ * Under capture of `stream` the call adds the whole render to the graph (the library's own stream joins the capture through
+ * the events the call records on either side) and runs nothing; replays of the graph share the array like calls do.
+ * Returns after the work is enqueued; the caller synchronises. */
 rt_status rt_render_device_noalloc(rt_scene* scene, const rt_camera* camera, const rt_image_options* image_options,
                                    const rt_render_options* render_options, double* d_mean_out);
 

@@ -131,6 +131,7 @@ struct SceneView {
     uint32_t n_spheres, n_rects, n_boxes, n_xforms, n_textures, n_images, n_perm_tables;
     uint32_t lds_scene_bytes;  // bytes those tables take in LDS behind the node array (each 16-byte aligned); 0 = leave them in global memory
     uint32_t side_rounding;    // some primitive's hit points need side_of_surface (scene_needs_side_rounding); the kernels come in two builds, with and without
+    uint32_t fp32_planes;      // no medium can be hit in this scene: the hit points of unwrapped boxes and rectangles are formed in fp32 (prim_surface)
 };
 
 // Rectangles and boxes as the kernels hold them: every f64 coordinate of the description as an fp32 value `hi` and an
@@ -479,11 +480,19 @@ RT_HD void local_surface(const SceneView& S, const rt_prim& P, D3 o, D3 d, float
     } else if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
         const rt_sphere sp = S.spheres[P.geom_index];
         const bool moving = P.geom == RT_GEOM_MOVING_SPHERE;
+        // The accepted t is the root rounded to fp32: taken as it is, the point lies up to |d| t 2^-24 along the ray from
+        // the reference's, and the normal is off by that over the radius.  Where that could reach 1e-6 (t |d| > 16 r: small
+        // spheres seen from afar), and where surface coordinates are wanted (near a pole v moves by the square root of what
+        // the point moves by), the root is derived again in f64; elsewhere -- the wave as a whole, most of the time -- the
+        // rounded t does (the next ray's origin is rounded to fp32 anyway, which moves it further than this).
         double t64 = (double)t;
-        sphere_root(sp, moving, o, d, time, t64);
-        if (P.flags & RT_PRIM_BOTH_ROOTS) {  // the accepted t is the fp32 rounding of one of the two roots
-            const double far_root = sphere_far_root(sp, moving, o, d, time);
-            if (fabs(far_root - (double)t) < fabs(t64 - (double)t)) t64 = far_root;
+        const bool again = want_uv || t64 * t64 * dot(d, d) > 256.0 * sp.radius * sp.radius || !(t64 - t64 == 0.0);
+        if (RT_ANY_LANE(again)) if (again) {
+            sphere_root(sp, moving, o, d, time, t64);
+            if (P.flags & RT_PRIM_BOTH_ROOTS) {  // the accepted t is the fp32 rounding of one of the two roots
+                const double far_root = sphere_far_root(sp, moving, o, d, time);
+                if (fabs(far_root - (double)t) < fabs(t64 - (double)t)) t64 = far_root;
+            }
         }
         const D3 c = sphere_center(sp, moving, time);
         const D3 p = ray_at(o, d, t64);
@@ -565,6 +574,11 @@ inline bool scene_needs_side_rounding(const rt_scene_desc* D) {  // (host side)
     for (uint32_t i = 0; i < D->n_prims; ++i) if (plane_off_grid(D->prims[i])) return true;
     return false;
 }
+inline bool scene_tree_holds_a_medium(const rt_scene_desc* D) {  // (host side) some leaf's primitive is a ConstantMedium (inert media are left out of the tree)
+    for (uint32_t i = 0; i < D->n_bvh_nodes; ++i)
+        if (D->bvh[i].prim != RT_BVH_NONE && (D->prims[D->bvh[i].prim & ~RT_BVH_EXACT].flags & RT_PRIM_MEDIUM)) return true;
+    return false;
+}
 RT_HD float fp32_step(float f, bool up) {  // the neighbour of a finite f above / below it
     uint32_t b; memcpy(&b, &f, sizeof(b));
     if ((b & 0x7fffffffu) == 0u) b = up ? 1u : 0x80000001u;
@@ -591,6 +605,37 @@ RT_HD V3 side_of_surface(V3 point, uint32_t side, V3 n, bool leaves_along_n) {
 RT_HD void prim_surface(const SceneView& S, const rt_prim& P, uint32_t prim, V3 o, V3 d, float time, float t, int side, bool want_uv, bool want_in_vec, Hit& h) {
     h.t = t; h.prim = prim;
     h.in_vec = want_in_vec ? normed(d) : d;
+    // An unwrapped box or rectangle whose material reads no surface coordinates, in a scene without media: the point in fp32.
+    // The reference's point lies on the plane to an ulp or two of f64 (origin + direction * t, t the quotient of shape.rs:321), so
+    // its coordinate across the plane, rounded to fp32, is the plane's (for a plane that is not an fp32 number: the fp32 number
+    // next to it); the other two are origin + direction * t with the t the walk accepted (within two fp32 ulps of the quotient).
+    // What is lost is the residue of a few f64 ulps that the reference's point keeps off a plane standing at 0 (fp32 holds
+    // numbers that small).  Only a ConstantMedium can tell: its boundary queries run over (-inf, inf) and take a rectangle
+    // behind the ray for hit when the ray's ORIGIN lies within the extents (shape.rs:321-329, geometry.rs:340-346), so a ray
+    // leaving a floor under a medium's box is inside or outside that box by the sign of the residue.  Every other query starts at
+    // tmin = 0.001, where a plane a residue away from the origin is rejected on t alone.  Hence the scene-wide condition (the
+    // library sets fp32_planes iff the tree holds no medium); with media, and for wrapped shapes, the f64 path below stays.
+    const bool quick = S.fp32_planes != 0u && P.xf_count == 0 && !(P.flags & RT_PRIM_MEDIUM) && (P.geom == RT_GEOM_BOX || P.geom == RT_GEOM_RECT) && !want_uv;
+    if (quick) {
+        uint32_t axis; float plane; bool flip = (P.flags & RT_PRIM_FLIP) != 0;
+        if (P.geom == RT_GEOM_RECT) {
+            const DevRect& R = S.rects[P.geom_index];
+            axis = R.axis; plane = R.h;
+        } else {
+            const DevBox& B = S.boxes[P.geom_index];
+            axis = (uint32_t)(side >> 1);
+            const bool upper = (side & 1) != 0;
+            plane = axis == 0 ? (upper ? B.max[0] : B.min[0]) : (axis == 1 ? (upper ? B.max[1] : B.min[1]) : (upper ? B.max[2] : B.min[2]));
+            flip = flip != !upper;  // the x0 / y0 / z0 sides are Flipped (outward normals)
+        }
+        V3 pt = ray_at(o, d, t);
+        const bool ahead = t > 0.0f;
+        const float s = flip ? -1.0f : 1.0f;
+        h.point = v3(axis == 0 && ahead ? plane : pt.x, axis == 1 && ahead ? plane : pt.y, axis == 2 && ahead ? plane : pt.z);
+        h.normal = v3(axis == 0 ? s : 0.0f, axis == 1 ? s : 0.0f, axis == 2 ? s : 0.0f);
+        h.u = 0.0f; h.v = 0.0f; h.point_side = 0;
+        return;
+    }
     D3 lo = d3(o), ld = d3(d);
     to_local(S, P, lo, ld);
     D3 pt, n; double u, v;
@@ -1186,12 +1231,25 @@ RT_HD float turbulence3(const uint8_t* perm, const uint8_t* source, uint32_t rou
     return perlin3(source, v3(fmaf(dx, power, p.x), fmaf(dy, power, p.y), fmaf(dz, power, p.z)));
 }
 
+// Checkered (textures.rs:49-55): `sin(10 x) * sin(10 y) * sin(10 z) < 0` picks the odd texture.  Only the signs count:
+// sin(theta) < 0 iff floor(theta / pi) is odd, so the product is negative iff an odd number of the three floor(10 c / pi)
+// are odd -- unless a factor is zero or NaN (a coordinate that is 0, infinite or NaN), when the product is not below zero.
+// Three multiplications and six floors in f64 (10 c is exact there for an fp32 c; the quotient errs by 2e-16 of itself,
+// far less than the fp32 rounding of the point it is taken at) in place of three sines with their argument reductions.
+RT_HD bool floor_is_odd(double u) { const double k = floor(u), h = 0.5 * k; return h != floor(h); }
+RT_HD bool checker_odd(V3 p) {
+    const double ten_over_pi = 3.1830988618379067;
+    const bool plain = fabsf(p.x) > 0.0f && fabsf(p.x) < RT_INF_F && fabsf(p.y) > 0.0f && fabsf(p.y) < RT_INF_F && fabsf(p.z) > 0.0f && fabsf(p.z) < RT_INF_F;
+    const bool odd = (floor_is_odd((double)p.x * ten_over_pi) != floor_is_odd((double)p.y * ten_over_pi)) != floor_is_odd((double)p.z * ten_over_pi);
+    return plain && odd;
+}
+
 // Texture::color_at (textures.rs:46-78).
 RT_HD V3 texture_color(const SceneView& S, uint32_t tex, float u, float v, V3 p) {
     rt_texture T = S.textures[tex];
-    for (uint32_t depth = 0; T.kind == RT_TEX_CHECKERED && depth < RT_MAX_TEXTURE_NESTING; ++depth) {
-        bool odd = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z) < 0.0f;
-        T = S.textures[odd ? T.odd : T.even];
+    if (T.kind == RT_TEX_CHECKERED) {
+        const bool odd = checker_odd(p);
+        for (uint32_t depth = 0; T.kind == RT_TEX_CHECKERED && depth < RT_MAX_TEXTURE_NESTING; ++depth) T = S.textures[odd ? T.odd : T.even];
     }
     if (T.kind == RT_TEX_NOISE) {
         const V3 q = v3(p.x * T.scale, p.y * T.scale, p.z * T.scale);

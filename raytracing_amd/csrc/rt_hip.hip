@@ -364,6 +364,13 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
 #endif
 }
 
+#ifdef RT_SHADE_STATS
+// Analysis build only: what the waves of k_shade (hit records from k_traverse) hold, summed over all launches since the last
+// read.  Pairs (waves with at least one such lane, lanes): 0 all passes / live lanes, 1 hits, 2 misses, 3 spheres, 4 boxes,
+// 5 rectangles, 6 media, 7 behind wrappers, 8 surface coordinates wanted, 9 Lambertian with an inlined solid colour, 10 Lambertian
+// with a texture call, 11 metal, 12 dielectric, 13 light, 14 isotropic, 15 checker, 16 noise, 17 image texture, 18 moving spheres
+__device__ unsigned long long g_shade_stats[40];
+#endif
 // Workgroup size of k_shade.  Each workgroup pass ends in one atomic on the length of the next queue; at 256 threads
 // the rate of those atomics (all on one address) bounds the kernel, at 512 it runs within a few per cent of the same
 // kernel without compaction, which moves its ~100 bytes per segment at over half of the HBM peak.
@@ -518,6 +525,25 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_
                 const NtU2 h_ = __builtin_nontemporal_load(reinterpret_cast<const NtU2*>(&hits[at]));
                 hit = h_.y != RT_HIT_NONE; t = __uint_as_float(h_.x); prim = h_.y & 0x1FFFFFFFu; side = (int)(h_.y >> 29);
             }
+#ifdef RT_SHADE_STATS
+            if (MODE == SHADE_HITS) {
+                const ShadeRec R = S.shade[hit ? prim : 0u];
+                const uint32_t tk = (hit && (R.mat.kind == RT_MAT_LAMBERTIAN || R.mat.kind == RT_MAT_DIFFUSE_LIGHT || R.mat.kind == RT_MAT_ISOTROPIC) && !(R.mat.reserved[0] & RT_MAT_SOLID_INLINE))
+                                        ? S.textures[R.mat.texture].kind : 0xFFu;
+                const bool sphere = R.prim.geom <= RT_GEOM_MOVING_SPHERE, medium = (R.prim.flags & RT_PRIM_MEDIUM) != 0;
+                const bool c[19] = {true, hit, !hit, hit && sphere && !medium, hit && R.prim.geom == RT_GEOM_BOX && !medium, hit && R.prim.geom == RT_GEOM_RECT && !medium, hit && medium,
+                                    hit && R.prim.xf_count > 0, hit && !(R.mat.reserved[0] & RT_MAT_SKIP_UV), hit && R.mat.kind == RT_MAT_LAMBERTIAN && tk == 0xFFu,
+                                    hit && R.mat.kind == RT_MAT_LAMBERTIAN && tk != 0xFFu, hit && R.mat.kind == RT_MAT_METAL, hit && R.mat.kind == RT_MAT_DIELECTRIC,
+                                    hit && R.mat.kind == RT_MAT_DIFFUSE_LIGHT, hit && R.mat.kind == RT_MAT_ISOTROPIC, tk == RT_TEX_CHECKERED, tk == RT_TEX_NOISE, tk == RT_TEX_IMAGE,
+                                    hit && R.prim.geom == RT_GEOM_MOVING_SPHERE};
+                for (int k = 0; k < 19; ++k) {
+                    const unsigned long long m = __ballot(c[k]);
+                    if (m != 0ull && __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0u && c[k]) {
+                        atomicAdd(&g_shade_stats[2 * k], 1ull); atomicAdd(&g_shade_stats[2 * k + 1], (unsigned long long)__popcll(m));
+                    }
+                }
+            }
+#endif
             alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value);
             if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
             else to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
@@ -952,6 +978,7 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     V.n_textures = D->n_textures; V.n_images = D->n_images; V.n_perm_tables = D->n_perm_tables;
     V.lds_scene_bytes = 0;
     V.side_rounding = scene_needs_side_rounding(D) ? 1u : 0u;
+    V.fp32_planes = scene_tree_holds_a_medium(D) ? 0u : 1u;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
     for (auto& x : sc->side_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
@@ -1153,6 +1180,13 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     hipStream_t caller = ro->stream ? (hipStream_t)ro->stream : nullptr;
     hipStream_t stream = sc->own_stream;
     if (caller) {
+        // A stream of raised priority must not wait for work that streams of normal priority have yet to do: on this runtime
+        // its pending wait keeps them from being scheduled and neither side ever finishes (seen with a priority -1 stream of
+        // torch's pool behind a frame still being rendered: hipStreamSynchronize on it never returned; the same chain through a
+        // stream of priority 0 completes).  The caller's stream waits for the library's, which have normal priority.
+        int priority = 0;
+        HIP_TRY(hipStreamGetPriority(caller, &priority));
+        if (priority < 0) return fail(RT_ERR_UNSUPPORTED, "rt_render_options.stream has a raised priority: it would wait for the library's normal-priority streams, which this runtime never schedules past such a wait; pass a stream of default priority");
         HIP_TRY(hipEventRecord(sc->ev_in, caller));
         HIP_TRY(hipStreamWaitEvent(stream, sc->ev_in, 0));
     }
@@ -1487,6 +1521,16 @@ rt_status rt_debug_trav_stats(unsigned long long* out16) {
     unsigned long long zero[16] = {};
     HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trav_stats), sizeof(zero)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), zero, sizeof(zero)));
+    return RT_OK;
+}
+#endif
+
+#ifdef RT_SHADE_STATS
+// Analysis build only: reads and clears the wave statistics of k_shade.
+rt_status rt_debug_shade_stats(unsigned long long* out40) {
+    unsigned long long zero[40] = {};
+    HIP_TRY(hipMemcpyFromSymbol(out40, HIP_SYMBOL(g_shade_stats), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_stats), zero, sizeof(zero)));
     return RT_OK;
 }
 #endif

@@ -50,8 +50,13 @@ def gather_frames(local_mean: torch.Tensor, dst: int = 0, group=None) -> torch.T
     exists, a group of one included (the collective is then the identity, and a one-GPU box can exercise the RCCL call)."""
     if dist.is_available() and dist.is_initialized():
         if local_mean.is_cuda and dist.get_backend(group) == "gloo" and not os.environ.get("RT_GLOO_DEVICE_TENSORS"):
-            # rehearsals only (several ranks on one GPU, no RCCL): the frame goes through the host here, and gloo sums host
-            # tensors.  (Handed the device tensor, gloo stages it through pinned memory on streams of its own.)
+            # rehearsals only (several ranks on one GPU, no RCCL): the frame goes through the host here (a copy on the current
+            # stream, which waits for the frame), and gloo sums host tensors.  Handed the device tensor, gloo stages it through
+            # pinned memory on a HIGH-PRIORITY stream of torch's pool that it makes wait for the current stream; on this ROCm
+            # build a raised-priority stream waiting for normal-priority streams that still have work (the frame being rendered)
+            # is never released: its hipStreamSynchronize in gloo's worker thread does not return (tools/gloo_hang_replica.py
+            # shows it in one process without gloo; the same chain through a stream of priority 0 completes).  RCCL's process
+            # group uses streams of normal priority.
             host = local_mean.cpu()
             dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
             if dist.get_rank(group) == dst:

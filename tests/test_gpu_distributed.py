@@ -120,3 +120,20 @@ def test_calls_from_several_threads_on_one_handle(earth):
     for k in range(len(jobs)):
         for rep in range(3):
             assert np.array_equal(got[k][rep], want[k]), (k, rep)
+
+
+def test_a_stream_of_raised_priority_is_refused(earth):
+    """A high-priority stream made to wait for normal-priority streams that still have work never gets released on this runtime
+    (what hung gloo's staging of device tensors, which uses such a stream, behind a frame still being rendered): the library
+    refuses to be ordered with one instead of hanging the caller."""
+    sc, co = _example("cornell", earth)
+    cam = rt.Camera(co)
+    buf = torch.zeros((32, 32, 3), dtype=torch.float64, device="cuda")
+    high = torch.cuda.Stream(priority=-1)
+    with pytest.raises(_abi.RtError) as e:
+        sc.render_device(cam, rt.ImageOptions(32, 32, 4, 50), rt.RenderOptions(seed=1, stream=high.cuda_stream), buf.data_ptr())
+    assert e.value.status == _abi.RT_ERR_UNSUPPORTED
+    normal = torch.cuda.Stream(priority=0)
+    sc.render_device(cam, rt.ImageOptions(32, 32, 4, 50), rt.RenderOptions(seed=1, stream=normal.cuda_stream), buf.data_ptr())
+    normal.synchronize()
+    assert buf.any()

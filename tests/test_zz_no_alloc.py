@@ -1,5 +1,6 @@
 """rt_render_device_noalloc (include/rt_abi.h): the render out of the library's static device workspace must give the
-bytes of rt_render_device, call after call, whatever the previous call left in the workspace."""
+bytes of rt_render_device, call after call, whatever the previous call left in the workspace; it must take no device memory;
+and, captured into a HIP graph, every replay must give those bytes again."""
 import numpy as np
 import pytest
 import torch
@@ -35,6 +36,54 @@ def test_noalloc_render_matches_render_device(earth):
     sm, cs = rt.Scene.example("cornell_smoke", 1)
     ref, got = _both(sm, rt.Camera(cs), rt.ImageOptions(64, 64, 9, 50), 5, rank=1, world_size=3, tile_w=8, tile_h=4)
     assert np.array_equal(got, ref) and ref.any()
+
+
+def test_noalloc_render_takes_no_device_memory(earth):
+    """hipMemGetInfo's free bytes are the same before and after calls of the entry point (torch's caching allocator holds on to
+    what it has, so the library's own hipMalloc / hipFree would be the only thing to move them): frames of different sizes on a
+    handle whose allocated workspace (grown by rt_render_device) is smaller than what they need."""
+    sc, co = rt.Scene.example("final_scene", 1, earth)
+    cam = rt.Camera(co)
+    side = torch.cuda.Stream()
+    buf = torch.zeros((200, 200, 3), dtype=torch.float64, device="cuda")
+    sc.render_device(cam, rt.ImageOptions(16, 16, 2, 50), rt.RenderOptions(seed=1, stream=side.cuda_stream), buf.data_ptr())   # (a small allocated workspace)
+    sc.render_device_noalloc(cam, rt.ImageOptions(16, 16, 2, 50), rt.RenderOptions(seed=1, stream=side.cuda_stream), buf.data_ptr())
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for (h, w, spp) in ((200, 200, 12), (64, 96, 3), (200, 160, 30)):
+        sc.render_device_noalloc(cam, rt.ImageOptions(h, w, spp, 50), rt.RenderOptions(seed=2, stream=side.cuda_stream), buf.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0, (h, w, spp)
+    assert buf.any()
+
+
+def test_noalloc_render_under_graph_capture(earth):
+    """The call joins the library's own stream to the caller's with an event on either side and creates nothing, so a capture of
+    the caller's stream takes the whole render in: nothing runs during the capture, and every replay of the graph writes the
+    bytes of rt_render_device."""
+    sc, co = rt.Scene.example("final_scene", 1, earth)
+    cam = rt.Camera(co)
+    io = rt.ImageOptions(96, 128, 20, 50)
+    side = torch.cuda.Stream()
+    ref = torch.full((io.height, io.width, 3), float("nan"), dtype=torch.float64, device="cuda")
+    side.wait_stream(torch.cuda.current_stream())
+    sc.render_device(cam, io, rt.RenderOptions(seed=9, stream=side.cuda_stream), ref.data_ptr())
+    side.synchronize()
+    ref = ref.cpu().numpy()
+    assert np.isfinite(ref).all() and ref.any()
+    buf = torch.full((io.height, io.width, 3), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="relaxed"):
+        sc.render_device_noalloc(cam, io, rt.RenderOptions(seed=9, stream=side.cuda_stream), buf.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.isnan(buf).all()          # captured, not run
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), ref)
+        buf.fill_(float("nan"))
+        torch.cuda.synchronize()
 
 
 def test_noalloc_render_rejects_what_does_not_fit(earth):
