@@ -103,6 +103,9 @@ public:
     static Shape rectangle(const Point3& lower_left, const Point3& upper_right);                         // shape.rs:129
     static Shape new_box(const Point3& min, const Point3& max);                                          // shape.rs:157
     static Shape ConstantMedium(const Shape& boundary, double density);
+    // NOT in the reference: a medium whose boundary queries see the ray behind its origin where it is (RT_PRIM_MULTI_SCATTER in
+    // rt_abi.h), so that a path scatters inside it again and again; the reference's media scatter at most once per entry.
+    static Shape ConstantMediumMultiScatter(const Shape& boundary, double density);
     Shape flipped() const;                          // shape.rs:110
     Shape translated(const Vec3& offset) const;     // shape.rs:115
     Shape rotated(Axis axis, double angle) const;   // shape.rs:123 (degrees)

@@ -62,10 +62,16 @@ enum {
     RT_PRIM_INERT = 4u,  /* provably never hit (a medium whose boundary is a sphere: the second
                             boundary query of shape.rs:390 repeats the near root); kept in the
                             list so primitive ids stay stable, left out of the BVH */
-    RT_PRIM_BOTH_ROOTS = 8u /* NOT the reference's behaviour (a variant for comparison with the book the crate follows): a
+    RT_PRIM_BOTH_ROOTS = 8u, /* NOT the reference's behaviour (a variant for comparison with the book the crate follows): a
                             sphere whose near root lies outside the ray interval is tried at its far root as well, so a ray that
                             starts inside a sphere hits it from within (glass refracts on the way out, a medium bounded by a
                             sphere scatters).  shape.rs:262-271 only ever takes the near root */
+    RT_PRIM_MULTI_SCATTER = 16u /* NOT the reference's behaviour either (media only): the two boundary queries of the medium
+                            (shape.rs:388-390) evaluate the ray behind its origin where it is instead of at the origin (Ray::at
+                            clamps t <= 0 to the origin, geometry.rs:340-346), so a ray that starts inside the boundary finds
+                            the way in behind it and the way out ahead, and a path scatters inside the medium as often as its
+                            free flights end there.  The reference's media scatter at most once per entry: from inside, the
+                            sides behind the origin all pass the extents test at the origin and both queries come back negative */
 };
 
 typedef struct rt_prim {

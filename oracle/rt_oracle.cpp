@@ -119,8 +119,9 @@ static inline Vec3 rotate(Vec3 s, int axis, double angle_deg) {
 // geometry.rs:333-347
 struct Ray {
     Vec3 origin, direction;
+    bool unclamped = false;  // NOT the reference: at() without its clamp (set only inside the boundary queries of a multi-scatter medium)
     Vec3 at(double t) const {
-        if (t <= 0.0) return origin;  // the reference clamps: t <= 0 returns the origin
+        if (t <= 0.0 && !unclamped) return origin;  // the reference clamps: t <= 0 returns the origin
         return origin + direction * t;
     }
 };
@@ -228,6 +229,7 @@ struct Shape {
     // Sphere / MovingSphere
     Vec3 center{}; double radius = 0; Ray ray{}; double start_time = 0, end_time = 0;
     bool both_roots = false;  // NOT the reference: try the far root when the near one is out of range (a variant for comparison)
+    bool multi_scatter = false;  // NOT the reference (ConstantMedium): boundary queries with Ray::at unclamped, so that a ray starting inside scatters again
     // Rectangle
     int axis = 0; double x0 = 0, y0 = 0, x1 = 0, y1 = 0, height = 0;
     // Box
@@ -359,13 +361,13 @@ bool Shape::intersect(const Ray& ray, double tmin, double tmax, double time, con
         }
         case Translated: {  // shape.rs:356-368
             CNT(translate);
-            Ray moved{ray.origin - offset, ray.direction};
+            Ray moved{ray.origin - offset, ray.direction, ray.unclamped};
             if (!inner->intersect(moved, tmin, tmax, time, ctx, prim, out)) return false;
             out->point = out->point + offset;
             return true;
         }
         case Rotated: {  // shape.rs:370-384
-            Ray rr{rotate(ray.origin, axis, -angle), rotate(ray.direction, axis, -angle)};
+            Ray rr{rotate(ray.origin, axis, -angle), rotate(ray.direction, axis, -angle), ray.unclamped};
             if (!inner->intersect(rr, tmin, tmax, time, ctx, prim, out)) { CNT(rotate_miss); return false; }
             CNT(rotate_hit);
             out->point = rotate(out->point, axis, angle);
@@ -376,8 +378,10 @@ bool Shape::intersect(const Ray& ray, double tmin, double tmax, double time, con
         case ConstantMedium: {  // shape.rs:386-423
             CNT(medium);
             IntersectionPoint ip1, ip2;
-            if (!inner->intersect(ray, -INF, INF, time, ctx, prim, &ip1)) return false;
-            if (!inner->intersect(ray, ip1.t + 0.001, INF, time, ctx, prim, &ip2)) return false;
+            Ray query = ray;
+            query.unclamped = multi_scatter;  // (the variant: the boundary is met behind the origin where it is, not at the origin)
+            if (!inner->intersect(query, -INF, INF, time, ctx, prim, &ip1)) return false;
+            if (!inner->intersect(query, ip1.t + 0.001, INF, time, ctx, prim, &ip2)) return false;
             ip1.t = rmax(ip1.t, tmin);
             ip2.t = rmin(ip2.t, tmax);
             if (ip1.t >= ip2.t) return false;
@@ -995,6 +999,10 @@ void* orc_flipped(void* s) { return new ShapeP(make_flipped(*(ShapeP*)s)); }
 void* orc_translated(void* s, const double* off) { return new ShapeP(make_translated(*(ShapeP*)s, v3(off))); }
 void* orc_rotated(void* s, int axis, double angle) { return new ShapeP(make_rotated(*(ShapeP*)s, axis, angle)); }
 void* orc_constant_medium(void* s, double density) { return new ShapeP(make_medium(*(ShapeP*)s, density)); }
+void* orc_constant_medium_multi(void* s, double density) {
+    auto m = std::make_shared<Shape>(*make_medium(*(ShapeP*)s, density)); m->multi_scatter = true;
+    return new ShapeP(m);
+}
 void orc_shape_free(void* s) { delete (ShapeP*)s; }
 
 void* orc_tex_solid(const double* c) { return new TexP(tex_solid(v3(c))); }

@@ -15,7 +15,7 @@ RT_ERR_INVALID_ARGUMENT, RT_ERR_EMPTY_SCENE, RT_ERR_UNSUPPORTED, RT_ERR_NO_DEVIC
 RT_RENDER_PROFILE, RT_RENDER_NO_TAIL, RT_RENDER_TAIL_ONLY, RT_RENDER_NODES_IN_GLOBAL, RT_RENDER_ONE_STREAM, RT_RENDER_RECALIBRATE, RT_RENDER_ONE_KERNEL, RT_RENDER_TWO_KERNELS = 1, 2, 4, 8, 16, 32, 64, 128
 RT_RENDER_KEEP_TREE = 256
 RT_GEOM_SPHERE, RT_GEOM_MOVING_SPHERE, RT_GEOM_RECT, RT_GEOM_BOX = 0, 1, 2, 3
-RT_PRIM_FLIP, RT_PRIM_MEDIUM, RT_PRIM_INERT, RT_PRIM_BOTH_ROOTS = 1, 2, 4, 8
+RT_PRIM_FLIP, RT_PRIM_MEDIUM, RT_PRIM_INERT, RT_PRIM_BOTH_ROOTS, RT_PRIM_MULTI_SCATTER = 1, 2, 4, 8, 16
 RT_MATF_FACE_NORMAL = 1
 RT_BVH_NONE, RT_BVH_EXACT = 0xFFFFFFFF, 0x80000000
 RT_NOISE_PERLIN, RT_NOISE_FBM, RT_NOISE_TURBULENCE = 0, 1, 2
@@ -144,6 +144,7 @@ def builder_symbols(prefix):
         prefix + "translated": (_P, [_P, _D3]),
         prefix + "rotated": (_P, [_P, C.c_int, C.c_double]),
         prefix + "constant_medium": (_P, [_P, C.c_double]),
+        prefix + "constant_medium_multi": (_P, [_P, C.c_double]),
         prefix + "shape_free": (None, [_P]),
         prefix + "shape_bound": (None, [_P, _D3, _D3]),
         prefix + "tex_solid": (_P, [_D3]),

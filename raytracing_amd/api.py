@@ -64,8 +64,10 @@ class Shape:
         return Shape("new_box", mn=tuple(mn), mx=tuple(mx))
 
     @staticmethod
-    def ConstantMedium(boundary, density):
-        return Shape("constant_medium", inner=boundary, density=float(density))
+    def ConstantMedium(boundary, density, multi_scatter=False):
+        """`multi_scatter` is NOT the reference's behaviour: the medium's boundary queries see the ray behind its origin where it is
+        (RT_PRIM_MULTI_SCATTER), so a ray that starts inside the boundary scatters again; the reference's media scatter once per entry."""
+        return Shape("constant_medium", inner=boundary, density=float(density), multi_scatter=bool(multi_scatter))
 
     def flipped(self):
         return Shape("flipped", inner=self)
@@ -101,7 +103,7 @@ class Shape:
             if k == "rotated":
                 return be.rotated(inner, kw["axis"], kw["angle"])
             if k == "constant_medium":
-                return be.constant_medium(inner, kw["density"])
+                return (be.constant_medium_multi if kw.get("multi_scatter") else be.constant_medium)(inner, kw["density"])
         finally:
             be.shape_free(inner)
         raise ValueError(k)

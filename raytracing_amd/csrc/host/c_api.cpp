@@ -41,6 +41,7 @@ void* rth_flipped(void* s) { return new Shape(((Shape*)s)->flipped()); }
 void* rth_translated(void* s, const double* off) { return new Shape(((Shape*)s)->translated(v3(off))); }
 void* rth_rotated(void* s, int axis, double angle) { return new Shape(((Shape*)s)->rotated((Axis)axis, angle)); }
 void* rth_constant_medium(void* s, double density) { return new Shape(Shape::ConstantMedium(*(Shape*)s, density)); }
+void* rth_constant_medium_multi(void* s, double density) { return new Shape(Shape::ConstantMediumMultiScatter(*(Shape*)s, density)); }
 void rth_shape_free(void* s) { delete (Shape*)s; }
 void rth_shape_bound(void* s, double* mn, double* mx) {
     geometry::BoundingBox b = *((Shape*)s)->bound();

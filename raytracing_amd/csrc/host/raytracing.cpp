@@ -60,6 +60,7 @@ struct Shape::Node {
     Kind kind;
     Point3 center; double radius = 0;                 // Sphere; MovingSphere: center = ray.origin
     bool both_roots = false;                          // Sphere: the far-root variant (not the reference's)
+    bool multi_scatter = false;                       // ConstantMedium: boundary queries without Ray::at's clamp (not the reference's)
     Vec3 motion; double start_time = 0, end_time = 0; // MovingSphere: ray.direction
     Axis axis = Axis::X; double x0 = 0, y0 = 0, x1 = 0, y1 = 0, height = 0;  // Rectangle; Rotated uses axis
     Point3 bmin, bmax;                                // Box
@@ -112,6 +113,10 @@ Shape Shape::new_box(const Point3& mn, const Point3& mx) {
 }
 Shape Shape::ConstantMedium(const Shape& boundary, double density) {
     auto n = std::make_shared<Node>(); n->kind = Kind::ConstantMedium; n->inner = boundary.n_; n->density = density;
+    return Shape(n);
+}
+Shape Shape::ConstantMediumMultiScatter(const Shape& boundary, double density) {
+    auto n = std::make_shared<Node>(); n->kind = Kind::ConstantMedium; n->inner = boundary.n_; n->density = density; n->multi_scatter = true;
     return Shape(n);
 }
 Shape Shape::flipped() const {
@@ -402,6 +407,7 @@ void Scene::Impl::add_object(const Object& obj) {
         } else if (cur->kind == K::ConstantMedium) {
             if (medium) throw std::invalid_argument("Scene: a ConstantMedium nested inside another ConstantMedium is not supported");
             medium = true; P.density = (float)cur->density; P.xf_outer = (uint32_t)(xforms.size() - P.xf_first);
+            if (cur->multi_scatter) P.flags |= RT_PRIM_MULTI_SCATTER;
             cur = cur->inner.get();
         } else break;
     }

@@ -132,6 +132,7 @@ struct SceneView {
     uint32_t lds_scene_bytes;  // bytes those tables take in LDS behind the node array (each 16-byte aligned); 0 = leave them in global memory
     uint32_t side_rounding;    // some primitive's hit points need side_of_surface (scene_needs_side_rounding); the kernels come in two builds, with and without
     uint32_t fp32_planes;      // no medium can be hit in this scene: the hit points of unwrapped boxes and rectangles are formed in fp32 (prim_surface)
+    uint32_t multi_scatter;    // some medium is flagged RT_PRIM_MULTI_SCATTER; the traversal kernel has a build without that code (the flag is then ignored: the host picks the build)
 };
 
 // Rectangles and boxes as the kernels hold them: every f64 coordinate of the description as an fp32 value `hi` and an
@@ -175,6 +176,10 @@ RT_HD double compd(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 // medium act on it (shape.rs:386-410).  Unfused, the residue is exactly 0 more often than not, as in the reference; a
 // fused multiply-add leaves it non-zero, half of the time negative, and darkens cornell_smoke's floor by up to 14 %.)
 RT_HD D3 ray_at(D3 o, D3 d, double t) { return (t <= 0.0) ? o : d3(d.x * t + o.x, d.y * t + o.y, d.z * t + o.z); }
+// Ray::at with the clamp at t <= 0 left out on request (the boundary queries of a medium flagged RT_PRIM_MULTI_SCATTER, which is
+// not the reference's behaviour).
+RT_HD V3 ray_at_opt(V3 o, V3 d, float t, bool unclamped) { return unclamped ? madd(o, d, t) : ray_at(o, d, t); }
+RT_HD D3 ray_at_opt(D3 o, D3 d, double t, bool unclamped) { return unclamped ? d3(d.x * t + o.x, d.y * t + o.y, d.z * t + o.z) : ray_at(o, d, t); }
 RT_HD D3 rotate_cs(D3 s, uint32_t kind, double c, double sn) {
     D3 o = s;
     if (kind == RT_XF_ROTATE_X) { o.y = s.y * c - s.z * sn; o.z = s.y * sn + s.z * c; }
@@ -305,12 +310,12 @@ RT_HD double sphere_far_root(const rt_sphere& sp, bool moving, D3 o, D3 dd, floa
 // Rectangle (shape.rs:309-332): inclusive interval and extents tests written so that NaN and
 // infinity flow exactly as in the reference.
 // `height_lo`: the remainder of the plane's coordinate (fp32 callers; the f64 callers pass the whole coordinate as `height`).
-template <class T, class VT>
+template <class T, class VT, bool UNCLAMPED = false>
 RT_HD bool rect_t(uint32_t axis, T x0, T y0, T x1, T y1, T height, T height_lo, VT o, VT d, T tmin, T tmax, T& t_out) {
     int p1, p2, oo; axis_perm(axis, p1, p2, oo);
     T t = ((height - get(o, oo)) + height_lo) / get(d, oo);
     if (t < tmin || t > tmax) return false;
-    VT pt = ray_at(o, d, t);
+    VT pt = ray_at_opt(o, d, t, UNCLAMPED);
     T a = get(pt, p1), b = get(pt, p2);
     if (a < x0 || a > x1 || b < y0 || b > y1) return false;
     t_out = t;
@@ -339,14 +344,14 @@ RT_HD void box_side(const DevBox& B, int k, uint32_t& axis, T& x0, T& y0, T& x1,
 }
 // Box = Vec<Shape>::intersect over the six sides with shrinking tmax (shape.rs:17-34):
 // the smallest accepted t wins and a later side wins an exact tie.
-template <class T, class VT>
+template <class T, class VT, bool UNCLAMPED = false>
 RT_HD bool box_t(const DevBox& B, VT o, VT d, T tmin, T tmax, T& t_out, int& side) {
     bool any = false;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         uint32_t axis; T x0, y0, x1, y1, h, h_lo, t;
         box_side<T>(B, k, axis, x0, y0, x1, y1, h, h_lo);
-        if (rect_t<T, VT>(axis, x0, y0, x1, y1, h, h_lo, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
+        if (rect_t<T, VT, UNCLAMPED>(axis, x0, y0, x1, y1, h, h_lo, o, d, tmin, tmax, t)) { tmax = t; t_out = t; side = k; any = true; }
     }
     return any;
 }
@@ -358,6 +363,7 @@ RT_HD void box_quotients(const DevBox& B, V3 o, V3 inv, float* q) {
     q[2] = ((B.min[1] - o.y) + B.min_lo[1]) * inv.y; q[3] = ((B.max[1] - o.y) + B.max_lo[1]) * inv.y;
     q[4] = ((B.min[2] - o.z) + B.min_lo[2]) * inv.z; q[5] = ((B.max[2] - o.z) + B.max_lo[2]) * inv.z;
 }
+template <bool UNCLAMPED = false>
 RT_HD bool box_sides_q(const DevBox& B, V3 o, V3 d, const float* q, float tmin, float tmax, float& t_out, int& side) {
     bool any = false;
 #pragma unroll
@@ -366,7 +372,7 @@ RT_HD bool box_sides_q(const DevBox& B, V3 o, V3 d, const float* q, float tmin, 
         box_side<float>(B, k, axis, x0, y0, x1, y1, h, h_lo);
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
         const float t = q[k];
-        const V3 pt = ray_at(o, d, t);
+        const V3 pt = ray_at_opt(o, d, t, UNCLAMPED);
         const float a = comp(pt, p1), b = comp(pt, p2);
         // no branches: the six sides run as straight code, their conditions as flags
         const bool ok = !(t < tmin || t > tmax) && !(a < x0 || a > x1 || b < y0 || b > y1);
@@ -374,21 +380,23 @@ RT_HD bool box_sides_q(const DevBox& B, V3 o, V3 d, const float* q, float tmin, 
     }
     return any;
 }
-template <>
-RT_HD bool box_t<float, V3>(const DevBox& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) {
+template <bool UNCLAMPED>
+RT_HD bool box_f32(const DevBox& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) {
     const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float q[6];
     box_quotients(B, o, inv, q);
-    return box_sides_q(B, o, d, q, tmin, tmax, t_out, side);
+    return box_sides_q<UNCLAMPED>(B, o, d, q, tmin, tmax, t_out, side);
 }
+template <> RT_HD bool box_t<float, V3, false>(const DevBox& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) { return box_f32<false>(B, o, d, tmin, tmax, t_out, side); }
+template <> RT_HD bool box_t<float, V3, true>(const DevBox& B, V3 o, V3 d, float tmin, float tmax, float& t_out, int& side) { return box_f32<true>(B, o, d, tmin, tmax, t_out, side); }
 
 // The f64 form (boxes behind Translated / Rotated wrappers, boundaries of media): the same six sides with the plane parameters
 // formed as (bound - origin) * (1 / direction), the three reciprocals refined to within an ulp or two (rcp_exact_at_zero).  The
 // reference divides (shape.rs:321); the product differs from the quotient by a couple of f64 ulps, nine orders of magnitude
 // below the fp32 rounding of the accepted t, and goes to +-inf / NaN for a zero direction component exactly as the quotient
 // does.  Six f64 divisions were two thirds of the instructions of this test.
-template <>
-RT_HD bool box_t<double, D3>(const DevBox& B, D3 o, D3 d, double tmin, double tmax, double& t_out, int& side) {
+template <bool UNCLAMPED>
+RT_HD bool box_f64(const DevBox& B, D3 o, D3 d, double tmin, double tmax, double& t_out, int& side) {
     const D3 inv = d3(rcp_exact_at_zero(d.x), rcp_exact_at_zero(d.y), rcp_exact_at_zero(d.z));
     bool any = false;
 #pragma unroll
@@ -397,16 +405,18 @@ RT_HD bool box_t<double, D3>(const DevBox& B, D3 o, D3 d, double tmin, double tm
         box_side<double>(B, k, axis, x0, y0, x1, y1, h, h_lo);
         int p1, p2, oo; axis_perm(axis, p1, p2, oo);
         const double t = (h - compd(o, oo)) * compd(inv, oo);
-        const D3 pt = ray_at(o, d, t);
+        const D3 pt = ray_at_opt(o, d, t, UNCLAMPED);
         const double a = compd(pt, p1), b = compd(pt, p2);
         const bool ok = !(t < tmin || t > tmax) && !(a < x0 || a > x1 || b < y0 || b > y1);
         tmax = ok ? t : tmax; t_out = ok ? t : t_out; side = ok ? k : side; any = any || ok;
     }
     return any;
 }
+template <> RT_HD bool box_t<double, D3, false>(const DevBox& B, D3 o, D3 d, double tmin, double tmax, double& t_out, int& side) { return box_f64<false>(B, o, d, tmin, tmax, t_out, side); }
+template <> RT_HD bool box_t<double, D3, true>(const DevBox& B, D3 o, D3 d, double tmin, double tmax, double& t_out, int& side) { return box_f64<true>(B, o, d, tmin, tmax, t_out, side); }
 
 // Ray parameter of the innermost shape for a ray already in its frame.
-template <class T, class VT>
+template <class T, class VT, bool UNCLAMPED = false>
 RT_HD bool geom_t(const SceneView& S, const rt_prim& P, VT o, VT d, T tmin, T tmax, float time, T& t, int& side) {
     side = 0;
     if (P.geom == RT_GEOM_SPHERE || P.geom == RT_GEOM_MOVING_SPHERE) {
@@ -422,10 +432,10 @@ RT_HD bool geom_t(const SceneView& S, const rt_prim& P, VT o, VT d, T tmin, T tm
     }
     if (P.geom == RT_GEOM_RECT) {
         const DevRect R = S.rects[P.geom_index];
-        return rect_t<T, VT>(R.axis, coord<T>(R.x0, R.x0_lo), coord<T>(R.y0, R.y0_lo), coord<T>(R.x1, R.x1_lo), coord<T>(R.y1, R.y1_lo), coord<T>(R.h, R.h_lo),
-                             sizeof(T) == sizeof(float) ? (T)R.h_lo : (T)0, o, d, tmin, tmax, t);
+        return rect_t<T, VT, UNCLAMPED>(R.axis, coord<T>(R.x0, R.x0_lo), coord<T>(R.y0, R.y0_lo), coord<T>(R.x1, R.x1_lo), coord<T>(R.y1, R.y1_lo), coord<T>(R.h, R.h_lo),
+                                        sizeof(T) == sizeof(float) ? (T)R.h_lo : (T)0, o, d, tmin, tmax, t);
     }
-    return box_t<T, VT>(S.boxes[P.geom_index], o, d, tmin, tmax, t, side);
+    return box_t<T, VT, UNCLAMPED>(S.boxes[P.geom_index], o, d, tmin, tmax, t, side);
 }
 
 // Intersection::intersect reduced to the accepted ray parameter (plus the box side) for a ray in the
@@ -434,8 +444,15 @@ template <class T, class VT>
 RT_HD bool local_t(const SceneView& S, const rt_prim& P, uint32_t prim, VT o, VT d, T tmin, T tmax, float time, const DrawKey& key, T& t, int& side) {
     if (!(P.flags & RT_PRIM_MEDIUM)) return geom_t<T, VT>(S, P, o, d, tmin, tmax, time, t, side);
     T t1, t2; int s_;
-    if (!geom_t<T, VT>(S, P, o, d, -Lim<T>::inf(), Lim<T>::inf(), time, t1, s_)) return false;
-    if (!geom_t<T, VT>(S, P, o, d, t1 + (T)0.001, Lim<T>::inf(), time, t2, s_)) return false;
+    // (RT_PRIM_MULTI_SCATTER, not the reference's behaviour: the two boundary queries see the points behind the origin where they
+    // are, so a ray that starts inside the boundary finds the way in behind it and the way out ahead of it, and scatters again)
+    if (S.multi_scatter != 0u && (P.flags & RT_PRIM_MULTI_SCATTER)) {
+        if (!geom_t<T, VT, true>(S, P, o, d, -Lim<T>::inf(), Lim<T>::inf(), time, t1, s_)) return false;
+        if (!geom_t<T, VT, true>(S, P, o, d, t1 + (T)0.001, Lim<T>::inf(), time, t2, s_)) return false;
+    } else {
+        if (!geom_t<T, VT>(S, P, o, d, -Lim<T>::inf(), Lim<T>::inf(), time, t1, s_)) return false;
+        if (!geom_t<T, VT>(S, P, o, d, t1 + (T)0.001, Lim<T>::inf(), time, t2, s_)) return false;
+    }
     t1 = Lim<T>::mx(t1, tmin);
     t2 = Lim<T>::mn(t2, tmax);
     if (t1 >= t2) return false;
@@ -572,6 +589,10 @@ RT_HD bool plane_off_grid(const rt_prim& P) {
 }
 inline bool scene_needs_side_rounding(const rt_scene_desc* D) {  // (host side)
     for (uint32_t i = 0; i < D->n_prims; ++i) if (plane_off_grid(D->prims[i])) return true;
+    return false;
+}
+inline bool scene_has_multi_scatter_media(const rt_scene_desc* D) {  // (host side)
+    for (uint32_t i = 0; i < D->n_prims; ++i) if ((D->prims[i].flags & RT_PRIM_MEDIUM) && (D->prims[i].flags & RT_PRIM_MULTI_SCATTER)) return true;
     return false;
 }
 inline bool scene_tree_holds_a_medium(const rt_scene_desc* D) {  // (host side) some leaf's primitive is a ConstantMedium (inert media are left out of the tree)

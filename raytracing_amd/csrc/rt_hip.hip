@@ -179,10 +179,13 @@ __device__ __forceinline__ const T* stage_table(const T* src, uint32_t count, un
 }
 // SIDES: the build of the kernel for scenes with hit points that need side_of_surface (rt_core.h); the other build has that
 // code folded away (its mere presence cost the scenes without such surfaces 1 to 2 %: registers, spills).
-template <bool NODES_IN_LDS, bool SIDES = false>
+// MULTI = false: the build for scenes without media flagged RT_PRIM_MULTI_SCATTER has that code folded away as well (k_traverse
+// only: its register allocation is tight enough for the extra paths to cost spills in the walk itself).
+template <bool NODES_IN_LDS, bool SIDES = false, bool MULTI = true>
 __device__ __forceinline__ SceneView stage_nodes(const SceneView& S, uint4* lds) {
     SceneView V = S;
     V.side_rounding = SIDES ? 1u : 0u;
+    if (!MULTI) V.multi_scatter = 0u;
     if (NODES_IN_LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(S.bvh);
         for (uint32_t k = threadIdx.x; k < 2u * (S.n_bvh_nodes + 1u); k += blockDim.x) lds[k] = src[k];  // with the sentinel slot
@@ -237,14 +240,14 @@ __device__ unsigned long long g_trav_stats[16];
 #else
 #define RT_STAT(k, v)
 #endif
-template <bool NODES_IN_LDS>
+template <bool NODES_IN_LDS, bool MULTI = false>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LDS ? 6 : 1) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
                                                                                    uint2* hits, uint32_t bounce) {
     extern __shared__ uint4 lds_nodes[];
     // (the workgroup's ray counter stands behind the node array, so that the array starts at LDS address 0 and a node's
     // byte offset is its address)
     uint32_t& next_ray = *reinterpret_cast<uint32_t*>(lds_nodes + (NODES_IN_LDS ? 2u * (S0.n_bvh_nodes + 1u) : 0u));
-    const SceneView S = stage_nodes<NODES_IN_LDS>(S0, lds_nodes);
+    const SceneView S = stage_nodes<NODES_IN_LDS, false, MULTI>(S0, lds_nodes);
     const uint32_t n_front = count_ptr[0], count = n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_nodes = S.n_bvh_nodes * RT_NODE_STRIDE;  // the sentinel's position: node positions are byte offsets
@@ -979,6 +982,7 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     V.lds_scene_bytes = 0;
     V.side_rounding = scene_needs_side_rounding(D) ? 1u : 0u;
     V.fp32_planes = scene_tree_holds_a_medium(D) ? 0u : 1u;
+    V.multi_scatter = scene_has_multi_scatter_media(D) ? 1u : 0u;
     for (int c = 0; c < 3; ++c) V.background[c] = (float)D->background[c];
     hipError_t e = hipStreamCreateWithFlags(&sc->own_stream, hipStreamNonBlocking);
     for (auto& x : sc->side_stream) if (e == hipSuccess) e = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
@@ -1003,9 +1007,11 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     }
     if (sc->nodes_fit_lds) {
         hipFuncAttributes fa;
-        e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_traverse<true>));
-        if (e == hipSuccess && fa.sharedSizeBytes != 0) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array"); }
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
+        for (const void* f : {reinterpret_cast<const void*>(&k_traverse<true, false>), reinterpret_cast<const void*>(&k_traverse<true, true>)}) {
+            if (e == hipSuccess) e = hipFuncGetAttributes(&fa, f);
+            if (e == hipSuccess && fa.sharedSizeBytes != 0) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array"); }
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
+        }
         const void* const walkers[] = {reinterpret_cast<const void*>(&k_tail<true, false>), reinterpret_cast<const void*>(&k_tail<true, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_WALK, false>), reinterpret_cast<const void*>(&k_shade<SHADE_WALK, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true>),
@@ -1288,6 +1294,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         hipStream_t stream; PassParams P; RayQueue q[2]; uint2* hits; uint32_t* counts; float4* values; int cur;
     };
     const bool sides = sc->view.side_rounding != 0u;  // (which build of the shading kernels: see stage_nodes)
+    const bool multi = sc->view.multi_scatter != 0u;  // (which build of the traversal kernel: see stage_nodes)
+    const auto traverse_lds = multi ? &k_traverse<true, true> : &k_traverse<true, false>;
+    const auto traverse_global = multi ? &k_traverse<false, true> : &k_traverse<false, false>;
     const auto tail_lds = sides ? &k_tail<true, true> : &k_tail<true, false>;
     const auto tail_global = sides ? &k_tail<false, true> : &k_tail<false, false>;
     const auto shade_scan = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true> : &k_shade<SHADE_SCAN, false, true>)
@@ -1298,9 +1307,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     const auto shade_hits = sides ? &k_shade<SHADE_HITS, true> : &k_shade<SHADE_HITS, false>;
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)
-            hipLaunchKernelGGL(k_traverse<true>, dim3(trav_grid), dim3(RT_TRAV_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+            hipLaunchKernelGGL(traverse_lds, dim3(trav_grid), dim3(RT_TRAV_BS), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
         else
-            hipLaunchKernelGGL(k_traverse<false>, dim3(grid), dim3(RT_BS), RT_LDS_BEHIND_NODES, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
+            hipLaunchKernelGGL(traverse_global, dim3(grid), dim3(RT_BS), RT_LDS_BEHIND_NODES, h.stream, sc->view, h.P, h.q[h.cur], h.counts + b, h.hits, b);
     };
     auto launch_tail = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
         if (nodes_in_lds)

@@ -14,6 +14,7 @@ pub const RT_PRIM_FLIP: u8 = 1;
 pub const RT_PRIM_MEDIUM: u8 = 2;
 pub const RT_PRIM_INERT: u8 = 4;
 pub const RT_PRIM_BOTH_ROOTS: u8 = 8; // not the reference's behaviour; the facade never sets it
+pub const RT_PRIM_MULTI_SCATTER: u8 = 16; // not the reference's behaviour either (media that scatter more than once per entry); never set here
 pub const RT_MATF_FACE_NORMAL: u32 = 1; // likewise (rt_material.reserved[1])
 
 pub const RT_NOISE_PERLIN: u32 = 0;

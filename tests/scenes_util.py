@@ -38,6 +38,9 @@ def shape_zoo():
         ("sphere_both_roots", S.Sphere((1.0, 2.0, -3.0), 2.5, both_roots=True)),
         ("sphere_both_roots_rot_y_trans", S.Sphere((0, 0, 0), 2.0, both_roots=True).rotate(rt.AXIS_Y, 45.0).translated((1, -1, 2))),
         ("medium_sphere_both_roots", S.ConstantMedium(S.Sphere((0, 0, 0), 3.0, both_roots=True), 0.5)),
+        # media that scatter again from within (RT_PRIM_MULTI_SCATTER; not the reference's behaviour either)
+        ("medium_cube_multi", S.ConstantMedium(S.new_box((-2, -2, -2), (2, 2, 2)), 0.4, multi_scatter=True)),
+        ("medium_wrapped_multi", S.ConstantMedium(S.new_box((-1, -1, -1), (1, 1, 1)).rotated(rt.AXIS_Z, 30.0), 0.8, multi_scatter=True).rotated(rt.AXIS_X, 20.0).translated((1, 2, 3))),
     ]
 
 
@@ -190,6 +193,29 @@ def far_root_variant_scene():
     co = dict(aperture=0.05, aspect_ratio=1.5, focus_distance=9.0, looking_at=(0.0, 1.0, 0.0), origin=(0.0, 2.0, 9.0), shutter_close=1.0, shutter_open=0.0,
               vfov=30.0, vup=(0.0, 1.0, 0.0))
     return objects, (0.7, 0.8, 1.0), co
+
+
+def multi_scatter_scene():
+    """Cornell's room with two boxes of smoke that scatter a path as often as its free flights end inside them
+    (RT_PRIM_MULTI_SCATTER: NOT the reference's behaviour, whose media scatter at most once per entry): one unwrapped, one
+    behind a rotation and a translation, dense enough for several scatterings per crossing."""
+    import raytracing_amd as rt
+    T, M, S = rt.Texture, rt.Material, rt.Shape
+    white, red, green = (M.Lambertian(T.SolidColor(c)) for c in ((0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15)))
+    objects = [
+        rt.Object(S.rectangle((0, 0, 0), (0, 555, 555)), red),
+        rt.Object(S.rectangle((555, 0, 0), (555, 555, 555)).flipped(), green),
+        rt.Object(S.rectangle((0, 0, 0), (555, 0, 555)), white),
+        rt.Object(S.rectangle((0, 555, 0), (555, 555, 555)).flipped(), white),
+        rt.Object(S.rectangle((0, 0, 555), (555, 555, 555)).flipped(), white),
+        rt.Object(S.rectangle((113, 554, 127), (443, 554, 432)), M.DiffuseLight(T.SolidColor((7, 7, 7)))),
+        rt.Object(S.ConstantMedium(S.new_box((100, 50, 100), (260, 330, 260)), 0.02, multi_scatter=True), M.Isotropic(T.SolidColor((0.9, 0.9, 0.9)))),
+        rt.Object(S.ConstantMedium(S.new_box((0, 0, 0), (165, 165, 165)).rotated(1, -18.0).translated((300, 20, 165)), 0.03, multi_scatter=True),
+                  M.Isotropic(T.SolidColor((0.2, 0.4, 0.9)))),
+    ]
+    co = dict(aperture=0.0, aspect_ratio=1.0, focus_distance=10.0, looking_at=(278.0, 278.0, 0.0), origin=(278.0, 278.0, -800.0), shutter_close=1.0, shutter_open=0.0,
+              vfov=40.0, vup=(0.0, 1.0, 0.0))
+    return objects, (0.0, 0.0, 0.0), co
 
 
 def zoo_room():

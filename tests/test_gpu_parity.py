@@ -521,6 +521,42 @@ def test_noise_kinds_beyond_perlin():
         bad.device()
 
 
+def test_multi_scatter_media_variant():
+    """Media flagged RT_PRIM_MULTI_SCATTER (NOT the reference's behaviour): closest hits along the scene's paths (many of which
+    start inside the smoke) and the image with shared random streams, against the oracle built with the same switch; the same
+    scene with the reference's media traces fewer segments (its paths scatter once per entry and leave)."""
+    from scenes_util import multi_scatter_scene
+    objects, background, co_kw = multi_scatter_scene()
+    sc, osc = rt.Scene(objects, background), OracleScene(objects, background)
+    assert sum(1 for i in range(sc.desc.n_prims) if sc.desc.prims[i].flags & _abi.RT_PRIM_MULTI_SCATTER) == 2
+    co = rt.CameraOptions(**co_kw)
+    oco = co.to_c()
+    rng = np.random.default_rng(21)
+    inside_hits = 0
+    for b, (o, d, t) in enumerate(path_rays(osc, oco, 48, 48, 6, 2000, 6, rng)):
+        ho = osc.intersect(o, d, t, seed=6)
+        hg = sc.intersect_batch(o, d, t, seed=6)
+        compare_hits(hg, ho, "multi-scatter scene", allow_flag_mismatch=1e-3, origins=o)
+        if b > 0:   # rays that start on a scattering point inside a medium (normal (1, 0, 0), shape.rs:413) and scatter there again
+            inside_hits += int(((ho["hit"] == 1) & (ho["prim"] >= 6)).sum())
+    assert inside_hits > 200
+    cam = rt.Camera(co)
+    w, h, spp = 80, 80, 48
+    rgb, mean = sc.render(cam, rt.ImageOptions(h, w, spp, 50), rt.RenderOptions(seed=1), want_mean=True)
+    a, amean, _, _ = osc.render(oco, w, h, spp, 50, seed=1, threads=16)
+    b2, _, _, _ = osc.render(oco, w, h, spp, 50, seed=2, threads=16)
+    floor = rmse(a, b2)
+    assert rmse(rgb, a) <= 0.5 * floor, (rmse(rgb, a), floor)
+    # the reference's media in the same room: another picture
+    plain = [rt.Object(rt.Shape.ConstantMedium(o.shape.kw["inner"], o.shape.kw["density"]), o.material) if o.shape.kind == "constant_medium" else o for o in objects]
+    sc1 = rt.Scene(plain, background)
+    segments = []
+    for scene in (sc, sc1):
+        scene.render(cam, rt.ImageOptions(h, w, spp, 50), rt.RenderOptions(seed=1, flags=_abi.RT_RENDER_PROFILE))
+        segments.append(scene.profile()["segments"])
+    assert segments[0] > 1.1 * segments[1], segments      # paths go on scattering inside the smoke instead of once per entry
+
+
 def test_far_root_and_facing_normal_variants():
     """A scene made of the switches that are NOT the reference's behaviour (RT_PRIM_BOTH_ROOTS, RT_MATF_FACE_NORMAL): closest hits
     and shading records along its paths and its image with shared random streams against the oracle built with the same switches;

@@ -350,6 +350,38 @@ def test_converged_fixtures_are_what_the_oracle_renders(earth):
         assert 0 < blk < 0.25 * pix, (name, pix, blk)
 
 
+def test_multi_scatter_medium_by_hand():
+    """RT_PRIM_MULTI_SCATTER (NOT the reference's behaviour) against the reference's medium, on a ray that starts inside the
+    boundary box.  Reference (shape.rs:386-410 with Ray::at's clamp, geometry.rs:340-346): the three sides behind the origin are
+    all 'hit' at the origin, both boundary queries come back negative and the medium does nothing.  Variant: the sides behind
+    the ray are met where they are, the first query finds the way in (t = -1), the second the way out (t = 3), and the free
+    flight is measured from tmin."""
+    S = rt.Shape
+    box = S.new_box((0, 0, 0), (4, 4, 4))
+    o, d, t0 = [[1, 2, 2]], [[1.0, 0.1, 0.2]], [0.0]
+    d32 = np.asarray(d[0], np.float32).astype(np.float64)      # (rays reach the oracle as the fp32 numbers the GPU would get)
+    length = float(np.linalg.norm(d32))
+    once, many = OracleShape(S.ConstantMedium(box, 0.5)), OracleShape(S.ConstantMedium(box, 0.5, multi_scatter=True))
+    for u in (0.9, 0.5, 0.3):
+        assert once.intersect(o, d, t0, 0.001, INF, medium_u=[u])[0]["hit"] == 0
+        h = many.intersect(o, d, t0, 0.001, INF, medium_u=[u])[0]
+        flight = -np.log(np.float32(u).astype(np.float64)) / 0.5
+        assert h["hit"] == 1 and abs(h["t"] - (0.001 + flight / length)) < 1e-12 and list(h["normal"]) == [1, 0, 0]
+        assert np.allclose(h["point"], np.array(o[0]) + d32 * h["t"], atol=1e-12)
+    # the way out is 3 - 0.001 ray units away: a flight longer than that leaves the box without scattering
+    u_far = float(np.exp(-0.5 * 3.1 * length))
+    assert many.intersect(o, d, t0, 0.001, INF, medium_u=[u_far])[0]["hit"] == 0
+    # a closer hit elsewhere cuts the way short (t2 = min(way out, tmax), shape.rs:397)
+    h = many.intersect(o, d, t0, 0.001, 1.0, medium_u=[0.9])[0]
+    assert h["hit"] == 1
+    assert many.intersect(o, d, t0, 0.001, 1.0, medium_u=[float(np.exp(-0.5 * 1.2 * length))])[0]["hit"] == 0
+    # from outside the two agree: a genuine way in and way out either way
+    for u in (0.9, 0.4):
+        a = once.intersect([[-3, 2, 2]], d, t0, 0.001, INF, medium_u=[u])[0]
+        b = many.intersect([[-3, 2, 2]], d, t0, 0.001, INF, medium_u=[u])[0]
+        assert a["hit"] == b["hit"] == 1 and a["t"] == b["t"]
+
+
 def test_far_root_and_facing_normal_variants_by_hand():
     """The two switches that are NOT the reference's behaviour (RT_PRIM_BOTH_ROOTS, RT_MATF_FACE_NORMAL), on cases worked by hand.
     The reference takes a sphere's near root only (shape.rs:262-271) and never turns a normal (materials.rs:28-113)."""

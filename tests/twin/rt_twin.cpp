@@ -39,6 +39,7 @@ struct TwinScene {
         make_shade_records(D, shade);
         V.side_rounding = scene_needs_side_rounding(D) ? 1u : 0u;
         V.fp32_planes = scene_tree_holds_a_medium(D) ? 0u : 1u;
+        V.multi_scatter = scene_has_multi_scatter_media(D) ? 1u : 0u;
         V.shade = shade.data(); V.textures = D->textures; V.images = D->images; V.texels = D->texels; V.perm = D->perm_tables;
         if (with_nodes) make_walk_nodes(D, nodes, g_sample_rays.size() ? &g_sample_rays : nullptr);
         V.bvh = nodes.data();

@@ -11,9 +11,12 @@ Per configuration and kernel (k_traverse, k_shade), summed over the launches of 
                    requests of wide coalesced reads at 64 bytes (MI355X_MICROARCH.md, HBM section); separate passes
   hbm_gbps         hbm_bytes / the kernel's summed duration in the trace run
   valu_lane_slots_per_segment   SQ_INSTS_VALU * 64 / path segments
+The json also names the sha256 of the kernel sources (rt_hip.hip, rt_core.h) of the tree the summary is made in -- run it in the
+tree whose library was measured: bench.py marks the counters stale when its own sources differ.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -61,7 +64,13 @@ def read_durations(d):
 
 
 def main(root, out_json, out_md):
-    doc = {"source": "rocprofv3 --pmc, one run per counter group (SQ_*, TCC_HIT/MISS, FETCH_SIZE, WRITE_SIZE) plus a --kernel-trace run, on "
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = hashlib.sha256()
+    for rel in ("raytracing_amd/csrc/rt_hip.hip", "raytracing_amd/csrc/rt_core.h"):  # (bench.py compares this with the sources it runs on)
+        with open(os.path.join(here, rel), "rb") as fh:
+            sha.update(fh.read())
+    doc = {"kernel_source_sha256": sha.hexdigest(),
+           "source": "rocprofv3 --pmc, one run per counter group (SQ_*, TCC_HIT/MISS, FETCH_SIZE, WRITE_SIZE) plus a --kernel-trace run, on "
                      "tools/prof_workload.py <config> <spp> (RT_RENDER_NO_TAIL | RT_RENDER_ONE_STREAM: one k_traverse and one k_shade launch per bounce; "
                      "the launches of its first frame of 1 spp, after which the tree is regrouped by sampled rays, are left out)",
            "correction": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB counters; gfx950 FETCH_SIZE counts half of wide coalesced reads)",
