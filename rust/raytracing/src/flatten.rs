@@ -6,7 +6,7 @@
 use crate::ffi::*;
 use crate::geometry::{Boundable, Shape, Vec3};
 use crate::materials::Material;
-use crate::textures::{identify_perlin, Texture};
+use crate::textures::{identify_noise, perlin_table, DeviceNoise, Texture};
 use crate::Object;
 
 #[derive(Default)]
@@ -96,6 +96,20 @@ impl Flat {
         flat
     }
 
+    /// Index of the first of `tables` in the scene's list of permutation tables, where they stand one behind the other
+    /// (appended unless that run of tables is there already).
+    fn add_perm_tables(&mut self, tables: &[[u8; 256]]) -> u32 {
+        let flat: Vec<u8> = tables.iter().flat_map(|t| t.iter().copied()).collect();
+        let have = self.perm_tables.len() / 256;
+        for first in 0..(have + 1).saturating_sub(tables.len()) {
+            if self.perm_tables[256 * first..256 * (first + tables.len())] == flat[..] {
+                return first as u32;
+            }
+        }
+        self.perm_tables.extend_from_slice(&flat);
+        have as u32
+    }
+
     fn add_texture(&mut self, texture: &Texture) -> u32 {
         let mut r = RtTexture::default();
         match texture {
@@ -109,17 +123,34 @@ impl Flat {
                 r.even = self.add_texture(even);
             }
             Texture::Noise { scale, noise } => {
-                let table = identify_perlin(noise.as_ref()).expect(
-                    "Texture::Noise: the device evaluates noise::Perlin only, and this function is not a Perlin of a known seed \
-                     (textures::register_perlin_seed adds seeds other than 0)",
+                let found = identify_noise(noise.as_ref()).expect(
+                    "Texture::Noise: the device evaluates noise::Perlin, noise::Fbm and noise::Turbulence<Perlin> with the crate's \
+                     starting parameters, and this function is none of them for a known seed (textures::register_perlin_seed adds \
+                     seeds other than 0)",
                 );
                 r.kind = RT_TEX_NOISE;
                 r.scale = *scale as f32;
-                let known = self.perm_tables.chunks(256).position(|t| t == &table[..]);
-                r.resource = known.unwrap_or_else(|| {
-                    self.perm_tables.extend_from_slice(&table);
-                    self.perm_tables.len() / 256 - 1
-                }) as u32;
+                match found {
+                    DeviceNoise::Perlin { table } => {
+                        r.odd = RT_NOISE_PERLIN;
+                        r.resource = self.add_perm_tables(&[table]);
+                    }
+                    DeviceNoise::Fbm { seed, octaves, lacunarity, persistence } => {
+                        // octave i reads the table i places behind the first (rt_abi.h)
+                        let tables: Vec<[u8; 256]> = (0..octaves).map(|i| perlin_table(seed.wrapping_add(i))).collect();
+                        r.odd = RT_NOISE_FBM | (octaves << 8);
+                        r.color = [lacunarity as f32, persistence as f32, 0.0];
+                        r.resource = self.add_perm_tables(&tables);
+                    }
+                    DeviceNoise::Turbulence { source, seed, roughness, lacunarity, persistence, power } => {
+                        // the three distortion functions read tables resource + c + i: seeds seed .. seed + roughness + 1 in a row
+                        let tables: Vec<[u8; 256]> = (0..roughness + 2).map(|i| perlin_table(seed.wrapping_add(i))).collect();
+                        r.odd = RT_NOISE_TURBULENCE | (roughness << 8);
+                        r.color = [lacunarity as f32, persistence as f32, power as f32];
+                        r.resource = self.add_perm_tables(&tables);
+                        r.even = self.add_perm_tables(&[source]);
+                    }
+                }
             }
             Texture::Image(image) => {
                 r.kind = RT_TEX_IMAGE;

@@ -61,14 +61,15 @@ macro_rules! triple {
         #[derive(Clone, Copy, Debug, PartialEq)]
         pub struct $name(pub [f64; 3]);
 
+        // (a slice, as in the reference, geometry.rs:52-64 and :131-143: `p[i]`, `p.iter()`, `p.len()` mean the same there and here)
         impl Deref for $name {
-            type Target = [f64; 3];
-            fn deref(&self) -> &[f64; 3] {
+            type Target = [f64];
+            fn deref(&self) -> &[f64] {
                 &self.0
             }
         }
         impl DerefMut for $name {
-            fn deref_mut(&mut self) -> &mut [f64; 3] {
+            fn deref_mut(&mut self) -> &mut [f64] {
                 &mut self.0
             }
         }

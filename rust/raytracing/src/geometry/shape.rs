@@ -13,6 +13,23 @@ pub trait Intersection {
     fn intersect(&self, ray: &Ray, interval: (f64, f64), time: f64) -> Option<IntersectionPoint>;
 }
 
+/// A list of things is hit where its nearest member is hit (the reference's impl, shape.rs:17-34, which `Shape::Box` uses for
+/// its six sides): the members are asked in order, each within what is left of the interval after the hits before it, so of
+/// two members hit at the same parameter the later one is reported (a rectangle accepts the end of its interval).
+impl<I: Intersection> Intersection for Vec<I> {
+    fn intersect(&self, ray: &Ray, interval: (f64, f64), time: f64) -> Option<IntersectionPoint> {
+        let (lower, mut upper) = interval;
+        let mut nearest = None;
+        for member in self {
+            if let Some(found) = member.intersect(ray, (lower, upper), time) {
+                upper = found.t;
+                nearest = Some(found);
+            }
+        }
+        nearest
+    }
+}
+
 /// Things that may have a bounding box.
 pub trait Boundable {
     fn bound(&self) -> Option<BoundingBox>;

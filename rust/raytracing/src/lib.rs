@@ -26,7 +26,7 @@ fn env_number<T: std::str::FromStr>(name: &str) -> Option<T> {
     std::env::var(name).ok().and_then(|v| v.parse().ok())
 }
 
-/// Computes a vector of byte values representing an image (3 bytes per pixel, rows from the top).
+/// Renders `scene` through `camera`: `3 * width * height` bytes, RGB, top row first (`src/lib.rs:18` of the reference).
 pub fn pixels(camera: &Camera, scene: &Scene, image_options: ImageOptions) -> Vec<u8> {
     let ImageOptions { height, width, samples_per_pixel, max_reflections } = image_options;
     let io = ffi::RtImageOptions { height, width, samples_per_pixel: samples_per_pixel as u64, max_reflections: max_reflections as u64 };
@@ -76,16 +76,16 @@ pub fn pixels(camera: &Camera, scene: &Scene, image_options: ImageOptions) -> Ve
     rgb
 }
 
-/// Settings for generating an image.
+/// Frame size and sampling effort of one `pixels` call (the reference's struct of the same name, `src/lib.rs:108-117`).
 #[derive(Debug, Clone, Copy)]
 pub struct ImageOptions {
-    /// The image's height
+    /// Rows of the frame.
     pub height: u32,
-    /// The images width
+    /// Columns of the frame.
     pub width: u32,
-    /// How many rays to sample and average for every pixel
+    /// Camera paths traced, and averaged, per pixel.
     pub samples_per_pixel: usize,
-    /// The maximum number of times a ray can be reflected or scattered
+    /// Longest path, in segments; a path still alive after that many contributes black.
     pub max_reflections: usize,
 }
 
@@ -93,7 +93,10 @@ pub struct ImageOptions {
 pub(crate) struct DeviceScene {
     pub(crate) handle: *mut ffi::RtScene,
 }
-// the library's scene handles are immutable after creation and may be used from any thread
+// Rendering changes a handle (its workspace grows with the frame, it learns a schedule, it regroups its tree), so the
+// library serialises the calls made on one handle: every entry point of include/rt_abi.h that takes a handle holds the
+// handle's own lock for the duration of the call.  Calls from several threads on one `Scene` are therefore safe and run
+// one after the other; `rt_scene_destroy` runs in `drop`, when no other reference exists.
 unsafe impl Send for DeviceScene {}
 unsafe impl Sync for DeviceScene {}
 
@@ -141,12 +144,12 @@ impl Scene {
     }
 }
 
-/// A combination of geometry and material
+/// One thing in a scene: where it is and what its surface does to a ray (`src/lib.rs:261-266` of the reference).
 #[derive(Clone, Debug)]
 pub struct Object {
-    /// The physical shape of the object
+    /// Geometry, wrappers included.
     pub shape: Shape,
-    /// The material of the object
+    /// Surface behaviour.
     pub material: Material,
 }
 
@@ -156,18 +159,18 @@ impl Boundable for Object {
     }
 }
 
-/// The result of a ray hitting an [`Object`]
+/// What a material makes of a hit (`src/lib.rs:300-306` of the reference): the path goes on, or it ends in a colour.
 pub enum RayHit {
-    /// The ray was scattered, resulting in a new ray and an attenuation value
+    /// The path continues along `ray`; its throughput is multiplied by `attenuation`.
     Scattered { ray: Ray, attenuation: Vec3 },
-    /// The ray hit a light source of a given color
+    /// The path ends here with this radiance (lights; also a metal's grazing miss, with black).
     Emitted(Vec3),
 }
 
 pub mod camera {
     use super::geometry::*;
 
-    /// A representation of a camera
+    /// Thin-lens camera with a shutter interval, in the derived form the render loop uses (`src/lib.rs:314-341`).
     #[derive(Debug, Clone, Copy)]
     pub struct Camera {
         aspect_ratio: f64,
@@ -183,7 +186,7 @@ pub mod camera {
     }
 
     impl Camera {
-        /// Creates a new camera from a [`CameraOptions`] struct
+        /// Viewport, lens and orthonormal frame from the user's description (`src/lib.rs:347-384`).
         pub fn new(options: CameraOptions) -> Self {
             let CameraOptions { aperture, aspect_ratio, focus_distance, looking_at, origin, shutter_close, shutter_open, vfov, vup } = options;
             let viewport_height = 2.0 * (vfov / 2.0).to_radians().tan();
@@ -212,26 +215,26 @@ pub mod camera {
         }
     }
 
-    /// A struct capturing the options needed to create a camera
+    /// The user's description of a camera; same fields, order and meaning as the reference's (`src/lib.rs:405-425`).
     #[derive(Debug, Clone, Copy)]
     pub struct CameraOptions {
-        /// The radius of the camera's aperture
+        /// Lens diameter (the lens radius is half of it); 0 is a pinhole.
         pub aperture: f64,
-        /// The aspect ratio of the camera's viewport
+        /// Viewport width over height.
         pub aspect_ratio: f64,
-        /// The distance at which things are in focus
+        /// Distance from `origin` to the plane of sharp focus.
         pub focus_distance: f64,
-        /// A point the camera is looking straight at
+        /// The view is centred on this point.
         pub looking_at: Point3,
-        /// The point the camera is situated at
+        /// Position of the lens centre.
         pub origin: Point3,
-        /// The time at which the shutter closes
+        /// End of the exposure: ray times are drawn from `[shutter_open, shutter_close)`.
         pub shutter_close: f64,
-        /// The time at which the shutter opens
+        /// Start of the exposure.
         pub shutter_open: f64,
-        /// The camera's vertical field of view in degrees
+        /// Vertical opening angle of the view, degrees.
         pub vfov: f64,
-        /// A vector describing the camera's "up" direction.
+        /// Which way is up in the picture (need not be orthogonal to the view direction).
         pub vup: Vec3,
     }
 }

@@ -62,7 +62,8 @@ impl Texture {
 // ------------------------------------------------------------------------------------------------------------------
 // What the device can evaluate of an opaque `dyn NoiseFn`.
 //
-// The device implements one noise function: the gradient noise of `noise::Perlin` (eight surflets attn^4 * (d . grad),
+// The device implements the gradient noise of `noise::Perlin` and two functions built on it (`noise::Fbm`,
+// `noise::Turbulence<Perlin>`: see `identify_noise` below).  The gradient noise: `noise::Perlin` (eight surflets attn^4 * (d . grad),
 // attn = 1 - |d|^2, scaled by 3.8898553255531074 and clamped to [-1, 1]) over a 256-entry permutation table that crosses
 // the C ABI.  A `dyn NoiseFn` does not say what it is, so the facade *identifies* it: for every candidate seed it builds
 // the table the way `noise` 0.6 builds `PermutationTable::new(seed)`, evaluates the formula above on the host in f64 at a
@@ -152,16 +153,92 @@ pub(crate) fn device_perlin(table: &[u8; 256], p: [f64; 3]) -> f64 {
     (total * 3.889_855_325_553_107_4).max(-1.0).min(1.0)
 }
 
-/// The permutation table under which the device's noise equals `noise`, if there is one among the candidates.
-pub(crate) fn identify_perlin(noise: &(dyn NoiseFn<[f64; 3]> + Sync + Send)) -> Option<[u8; 256]> {
-    let mut seeds = vec![0u32];
-    seeds.extend(CANDIDATE_SEEDS.lock().unwrap().iter().copied());
-    // 64 probe points spread over many lattice cells, off the lattice
-    let probes: Vec<[f64; 3]> = (0..64u32)
+/// The device's `RT_NOISE_FBM` on the host, in f64: octave `i` is the Perlin of seed `seed + i` at the point scaled by
+/// `lacunarity^i`, weighted `persistence^i` (`fbm3` in the kernels' rt_core.h).
+pub(crate) fn device_fbm(seed: u32, octaves: u32, lacunarity: f64, persistence: f64, p: [f64; 3]) -> f64 {
+    let (mut sum, mut weight, mut q) = (0.0, 1.0, p);
+    for i in 0..octaves {
+        sum += weight * device_perlin(&perlin_table(seed.wrapping_add(i)), q);
+        weight *= persistence;
+        q = [q[0] * lacunarity, q[1] * lacunarity, q[2] * lacunarity];
+    }
+    sum
+}
+
+/// The device's `RT_NOISE_TURBULENCE` on the host: the source Perlin at the point displaced, per coordinate, by `power` times
+/// an Fbm of seeds `seed`, `seed + 1`, `seed + 2` looked up at the point shifted by the crate's fixed fractions of 65536
+/// (`turbulence3` in rt_core.h).
+pub(crate) fn device_turbulence(source: &[u8; 256], seed: u32, roughness: u32, lacunarity: f64, persistence: f64, power: f64, p: [f64; 3]) -> f64 {
+    let u = 1.0 / 65536.0;
+    let shifts = [[12414.0, 65124.0, 31337.0], [26519.0, 18128.0, 60493.0], [53820.0, 11213.0, 44845.0]];
+    let mut q = p;
+    for c in 0..3 {
+        let at = [p[0] + shifts[c][0] * u, p[1] + shifts[c][1] * u, p[2] + shifts[c][2] * u];
+        q[c] = p[c] + power * device_fbm(seed.wrapping_add(c as u32), roughness, lacunarity, persistence, at);
+    }
+    device_perlin(source, q)
+}
+
+/// What the device evaluates in place of an opaque `dyn NoiseFn`.
+pub(crate) enum DeviceNoise {
+    Perlin { table: [u8; 256] },
+    Fbm { seed: u32, octaves: u32, lacunarity: f64, persistence: f64 },
+    Turbulence { source: [u8; 256], seed: u32, roughness: u32, lacunarity: f64, persistence: f64, power: f64 },
+}
+
+/// The lacunarity `noise::Fbm` starts with (and the distortion functions of `noise::Turbulence` with it).
+pub(crate) const NOISE_CRATE_LACUNARITY: f64 = std::f64::consts::PI * 2.0 / 3.0;
+
+fn probe_points() -> Vec<[f64; 3]> {
+    // 64 points spread over many lattice cells, off the lattice
+    (0..64u32)
         .map(|k| {
             let k = k as f64;
             [0.37 + 1.618 * k, -5.21 + 2.414 * k, 11.03 - 0.732 * k]
         })
-        .collect();
-    seeds.into_iter().map(perlin_table).find(|table| probes.iter().all(|p| (device_perlin(table, *p) - noise.get(*p)).abs() < 1e-9))
+        .collect()
+}
+
+fn candidate_seeds() -> Vec<u32> {
+    let mut seeds = vec![0u32];
+    seeds.extend(CANDIDATE_SEEDS.lock().unwrap().iter().copied());
+    seeds
+}
+
+/// The permutation table under which the device's noise equals `noise`, if there is one among the candidates.
+pub(crate) fn identify_perlin(noise: &(dyn NoiseFn<[f64; 3]> + Sync + Send)) -> Option<[u8; 256]> {
+    let probes = probe_points();
+    candidate_seeds().into_iter().map(perlin_table).find(|table| probes.iter().all(|p| (device_perlin(table, *p) - noise.get(*p)).abs() < 1e-9))
+}
+
+/// Which of the device's noise functions `noise` is, by the same probe-and-compare step: a Perlin of a candidate seed, else a
+/// `noise::Fbm` with the crate's starting lacunarity and persistence and 1 to 8 octaves, else a `noise::Turbulence<Perlin>`
+/// with the crate's starting power and a roughness of 1 to 4, each over the candidate seeds (source and distortion seeds
+/// alike).  Other settings are not guessed: the scene is refused rather than drawn with a stand-in.
+pub(crate) fn identify_noise(noise: &(dyn NoiseFn<[f64; 3]> + Sync + Send)) -> Option<DeviceNoise> {
+    if let Some(table) = identify_perlin(noise) {
+        return Some(DeviceNoise::Perlin { table });
+    }
+    let probes = probe_points();
+    let want: Vec<f64> = probes.iter().map(|p| noise.get(*p)).collect();
+    let same = |f: &dyn Fn([f64; 3]) -> f64| probes.iter().zip(&want).all(|(p, w)| (f(*p) - w).abs() < 1e-9);
+    let (lacunarity, persistence, power) = (NOISE_CRATE_LACUNARITY, 0.5, 1.0);
+    for seed in candidate_seeds() {
+        for octaves in (1..=8u32).rev() {
+            if same(&|p| device_fbm(seed, octaves, lacunarity, persistence, p)) {
+                return Some(DeviceNoise::Fbm { seed, octaves, lacunarity, persistence });
+            }
+        }
+    }
+    for source_seed in candidate_seeds() {
+        let source = perlin_table(source_seed);
+        for seed in candidate_seeds() {
+            for roughness in 1..=4u32 {
+                if same(&|p| device_turbulence(&source, seed, roughness, lacunarity, persistence, power, p)) {
+                    return Some(DeviceNoise::Turbulence { source, seed, roughness, lacunarity, persistence, power });
+                }
+            }
+        }
+    }
+    None
 }

@@ -156,6 +156,22 @@ def test_facade_restates_the_same_perlin_table_and_tree_rules():
     assert "s = [1u32, seed, seed, seed]" in tex and "s[4] = {1u, seed, seed, seed}" in host
 
 
+def test_facade_carries_the_reference_s_generic_impls_and_the_noise_kinds():
+    """Public impls of the reference that scene code can lean on (geometry.rs:52-64, :131-143; shape.rs:17-34), and the noise
+    functions beyond Perlin mapped with the constants and shifts the kernels use."""
+    geo, shape, tex, flat = read(SRC, "geometry.rs"), read(SRC, "geometry", "shape.rs"), read(SRC, "textures.rs"), read(SRC, "flatten.rs")
+    assert re.search(r"impl Deref for \$name \{\s*type Target = \[f64\];", geo)
+    assert re.search(r"impl<I: Intersection> Intersection for Vec<I>", shape) and re.search(r"impl<T: Boundable> Boundable for Vec<T>", shape)
+    core = read(ROOT, "raytracing_amd", "csrc", "rt_core.h")
+    for k in ("12414.0", "65124.0", "31337.0", "26519.0", "18128.0", "60493.0", "53820.0", "11213.0", "44845.0"):
+        assert k in tex and k + "f" in core, k
+    assert "RT_NOISE_FBM | (octaves << 8)" in flat and "RT_NOISE_TURBULENCE | (roughness << 8)" in flat
+    ffi = read(SRC, "ffi.rs")
+    assert re.search(r"RT_ABI_VERSION: u32 = 3;", ffi) and re.search(r"RT_PRIM_MULTI_SCATTER: u8 = 16;", ffi)
+    # the facade's claim that a scene handle may be shared between threads rests on the library's per-handle lock
+    assert "std::lock_guard<std::mutex> lock(sc->mutex)" in read(ROOT, "raytracing_amd", "csrc", "rt_hip.hip")
+
+
 def test_cargo_manifest_names_the_crate_and_its_dependencies():
     manifest = read(CRATE, "Cargo.toml")
     assert re.search(r'^name = "raytracing"$', manifest, re.M)
