@@ -51,7 +51,6 @@ DEPTH = 50
 CONFIGS = {"cornell": (600, 600, 1000, 8), "perlin": (1920, 1080, 1000, 4), "cornell_smoke": (800, 800, 4000, 8), "final_scene": (800, 800, 10000, 1410)}
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 vector peak
 PEAK_HBM_GBPS = 8000.0    # MI355X HBM3E peak
-PASS_PATHS = 64 << 20     # paths of a full pass (the library's automatic pass size)
 KERNEL_SOURCES = ("raytracing_amd/csrc/rt_hip.hip", "raytracing_amd/csrc/rt_core.h")
 
 # flops per operation, read off the reference's source lines (one per add/sub/mul/div/min/max/compare/sqrt/transcendental)
@@ -220,6 +219,7 @@ def main(argv=None):
 
     WIDTH, HEIGHT, SPP, n_objects = CONFIGS[args.config]
     spp = args.spp or SPP
+    PASS_PATHS = int(_abi.hip_lib().rt_auto_pass_paths())  # paths of a full pass (the library's automatic pass size)
     under_launcher = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -289,7 +289,7 @@ def main(argv=None):
         samples = WIDTH * HEIGHT * spp * args.steps
         value = samples / elapsed / 1e6
         # Per-kernel timing: a profiled render (HIP events around every launch, on the launch stream) of this rank's share at the
-        # sample count of one whole pass (64 M paths; 104 spp at 800x800 on one GPU), so that every launch of the profile is a
+        # sample count of one whole pass (128 M paths; 209 spp at 800x800 on one GPU), so that every launch of the profile is a
         # full-size one and a kernel trace of `bench.py --spp <that> --one-stream` averages over launches of exactly this kind.
         prof_spp = max(1, min(spp, PASS_PATHS // max(1, me["n_owned"])))
         prof_io = rt.ImageOptions(HEIGHT, WIDTH, prof_spp, DEPTH)

@@ -372,6 +372,9 @@ rt_status rt_get_profile(rt_scene* scene, rt_profile* out);
 int rt_device_count(void);
 const char* rt_last_error(void);
 uint32_t rt_abi_version(void);
+/* Paths (owned pixels x samples) the library puts in one pass when rt_render_options.samples_per_pass is 0; a frame of fewer
+ * paths is one pass.  No counterpart in the reference; for callers that size warm-up frames (the schedule is learnt per pass size). */
+uint64_t rt_auto_pass_paths(void);
 
 #ifdef __cplusplus
 }

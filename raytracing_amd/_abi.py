@@ -125,6 +125,7 @@ HIP_SYMBOLS = {
     "rt_device_count": (C.c_int, []),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_uint32, []),
+    "rt_auto_pass_paths": (C.c_uint64, []),
 }
 
 _P = C.c_void_p

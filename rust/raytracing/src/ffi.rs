@@ -243,6 +243,7 @@ extern "C" {
     pub fn rt_device_count() -> i32;
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_abi_version() -> u32;
+    pub fn rt_auto_pass_paths() -> u64;
 }
 
 /// The library's message for the last failed call on this thread.
