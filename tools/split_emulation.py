@@ -4,8 +4,8 @@ slowest rank's (the gather of a 15 MB frame over xGMI is microseconds against se
 
     python tools/split_emulation.py [spp] [tile] > profiles/<tag>_split_emulation.md
 
-Each share is first rendered at 128 spp (as bench.py's warm-up does: sizes the workspace, lets the library learn the share's
-schedule), then timed at the full sample count."""
+Each share is first rendered at the sample count of one full pass of the share plus a little (as bench.py's warm-up does: sizes
+the workspace, lets the library learn the schedule of passes of that size), then timed at the full sample count."""
 import sys
 import time
 sys.path.insert(0, '.')
@@ -21,7 +21,11 @@ buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
 
 
 def timed(rank, world):
-    for s in (128, spp):
+    from raytracing_amd import _abi
+    from raytracing_amd.distributed import owned_mask
+    n_owned = int(owned_mask(W, H, rank, world, tile, tile).sum())
+    warm = min(spp, int(_abi.hip_lib().rt_auto_pass_paths()) // max(n_owned, 1) + 24)   # one full pass of this share and a little, as bench.py warms up
+    for s in (warm, spp):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         sc.render_device(cam, rt.ImageOptions(H, W, s, 50), rt.RenderOptions(seed=1, rank=rank, world_size=world, tile_w=tile, tile_h=tile), buf.data_ptr())
