@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-/* 3: rt_profile grew (tail_from, two_stream_passes, pass_paths); rt_render_options.stream orders the render with the caller's
+/* 3: rt_profile grew (tail_from, two_stream_passes, pass_paths, two_bounce_passes); rt_render_options.stream orders the render with the caller's
  * stream instead of naming the launch stream; noise textures read rt_texture.odd / even / color; new RT_RENDER_* and RT_PRIM_*
  * bits.  rt_scene_create refuses a description that carries another version. */
 #define RT_ABI_VERSION 3u
@@ -361,10 +361,13 @@ typedef struct rt_profile {
     double tree_tests_by_area, tree_tests_sampled;
     /* The schedule of the last pass of the last render call (set by every call, profiled or not): the bounce from which the
      * tail kernel ran every remaining segment (max_reflections if it never did), how many passes of the call ran as two
-     * halves on two streams, and the number of paths of a full pass.  The schedule is learnt per (frame shape, pass size). */
+     * halves on two streams, and the number of paths of a full pass.  The schedule is learnt per (frame shape, pass size).
+     * two_bounce_passes: passes of the call whose first launch ran bounces 0 and 1 in the same lanes (scenes of a few leaves). */
     int32_t tail_from;
     uint32_t two_stream_passes;
     uint64_t pass_paths;
+    uint32_t two_bounce_passes;
+    uint32_t reserved;
 } rt_profile;
 rt_status rt_get_profile(rt_scene* scene, rt_profile* out);
 

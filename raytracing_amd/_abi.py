@@ -100,7 +100,8 @@ class rt_scatter(C.Structure):
 class rt_profile(C.Structure):
     _fields_ = [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("samples", C.c_uint64), ("segments", C.c_uint64),
                 ("traverse_segments", C.c_uint64), ("passes", C.c_uint64), ("tree_tests_by_area", C.c_double), ("tree_tests_sampled", C.c_double),
-                ("tail_from", C.c_int32), ("two_stream_passes", C.c_uint32), ("pass_paths", C.c_uint64)]
+                ("tail_from", C.c_int32), ("two_stream_passes", C.c_uint32), ("pass_paths", C.c_uint64),
+                ("two_bounce_passes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class camera_options(C.Structure):

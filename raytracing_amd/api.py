@@ -443,7 +443,8 @@ class Scene:
         _abi.check(self._hip.rt_get_profile(self.device(), C.byref(p)))
         out = {"samples": p.samples, "segments": p.segments, "traverse_segments": p.traverse_segments, "passes": p.passes,
                "tree_tests_by_area": p.tree_tests_by_area, "tree_tests_sampled": p.tree_tests_sampled,
-               "tail_from": p.tail_from, "two_stream_passes": p.two_stream_passes, "pass_paths": p.pass_paths}
+               "tail_from": p.tail_from, "two_stream_passes": p.two_stream_passes, "pass_paths": p.pass_paths,
+               "two_bounce_passes": p.two_bounce_passes}
         for k, name in enumerate(_abi.RT_K_NAMES):
             out[name + "_ms"] = p.kernel_ms[k]
             out[name + "_launches"] = p.kernel_launches[k]

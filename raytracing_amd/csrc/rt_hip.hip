@@ -383,6 +383,9 @@ __device__ unsigned long long g_shade_stats[40];
 #ifndef RT_SHADE_PRIO
 #define RT_SHADE_PRIO 3
 #endif
+#ifndef RT_SCAN_TWO
+#define RT_SCAN_TWO 1  // the first launch of a scanned pass runs two bounces: 0 never, 1 in scenes without long-test leaves, 2 always
+#endif
 #ifndef RT_SCAN_FIRST
 #define RT_SCAN_FIRST 1
 #endif
@@ -457,8 +460,11 @@ __device__ __forceinline__ bool scan_queue_end(const SceneView& S, const Ray& r)
 #define RT_SCAN_GRID_PER_CU 8u  // workgroups of a scanned bounce per CU (four are resident at a time)
 #endif
 __host__ __device__ constexpr uint32_t shade_bs(int mode) { return mode == 2 /* SHADE_SCAN */ ? 256u : RT_SHADE_BS; }
-template <int MODE, bool SIDES, bool LONG_LEAVES = false, bool FIRST = false>
-__global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+#ifndef RT_TWO_WAVES
+#define RT_TWO_WAVES 4
+#endif
+template <int MODE, bool SIDES, bool LONG_LEAVES = false, bool FIRST = false, bool TWO = false>
+__global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (TWO ? RT_TWO_WAVES : 4) : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
     constexpr uint32_t BS = shade_bs(MODE);
     extern __shared__ uint4 lds_nodes[];
@@ -501,14 +507,22 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? 4 : 5) k_
                 pixel = __float_as_uint(c.w);
                 key = make_key(P, path, pixel, bounce);
             }
-            float t = 0.0f; uint32_t prim = 0; int side = 0;
-            const bool hit = closest_hit_scan(S, r, live, 0.001f, key, t, prim, side);  // lib.rs:90: (0.001, inf)
-            if (live) {
-                V3 value;
-                alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value);
-                if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
-                else if (!LONG_LEAVES) to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
+            // TWO: the lanes run this bounce and the next before anything goes to the queue (a scattered ray stays in its lane;
+            // the caller's next launch is for bounce + 2 and reads the counters two places on).  Draws are keyed by (pixel,
+            // sample, bounce), so who runs a bounce changes no byte.
+            alive = live;
+#pragma nounroll
+            for (uint32_t k = 0; k < (TWO ? 2u : 1u); ++k) {
+                key.bounce = bounce + k;
+                float t = 0.0f; uint32_t prim = 0; int side = 0;
+                const bool hit = closest_hit_scan(S, r, alive, 0.001f, key, t, prim, side);  // lib.rs:90: (0.001, inf)
+                if (alive) {
+                    V3 value;
+                    alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + k + 1 >= P.max_depth, value);
+                    if (!alive) __builtin_nontemporal_store(NtF4{value.x, value.y, value.z, 0.0f}, reinterpret_cast<NtF4*>(&values[path]));
+                }
             }
+            if (alive && !LONG_LEAVES) to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
             if (LONG_LEAVES) to_front = alive && scan_queue_end(S, r);
         } else if (i < count) {
             const uint32_t at = queue_slot(i, n_front, P.n_paths);
@@ -1021,7 +1035,9 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, false, true>),
-                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, true>)};
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, true>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, false, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, false, true, true>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, true, true>)};
         for (const void* f : walkers) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
     }
@@ -1308,6 +1324,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                                               : (sides ? &k_shade<SHADE_SCAN, true, false> : &k_shade<SHADE_SCAN, false, false>);
     const auto shade_scan_first = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true, true> : &k_shade<SHADE_SCAN, false, true, true>)
                                                     : (sides ? &k_shade<SHADE_SCAN, true, false, true> : &k_shade<SHADE_SCAN, false, false, true>);
+    const auto shade_scan_first_two = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true, true, true> : &k_shade<SHADE_SCAN, false, true, true, true>)
+                                                        : (sides ? &k_shade<SHADE_SCAN, true, false, true, true> : &k_shade<SHADE_SCAN, false, false, true, true>);
     const auto shade_walk = sides ? &k_shade<SHADE_WALK, true> : &k_shade<SHADE_WALK, false>;
     const auto shade_hits = sides ? &k_shade<SHADE_HITS, true> : &k_shade<SHADE_HITS, false>;
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
@@ -1332,6 +1350,11 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         const bool readback = !fixed && (tail_from < 0 || profile || force_wavefront);
         // a scanned scene's first bounce makes its own camera rays (unless the pass goes to k_tail at once)
         const bool first_is_scan = RT_SCAN_FIRST && fused && scan && !(tail_from == 0 && !force_wavefront);
+        // ... and its second bounce too, in the same lanes, when nothing has to be known about the queue between the two.  Nearly
+        // every path has a second segment, so the lanes stay full, and 96 bytes per path stay out of memory (perlin, whose
+        // paths are 2.3 segments long: 10 890 -> 11 950 Msamples/s).  Not where the queue is ordered by long-test leaves: the
+        // second bounce would run unordered (cornell -2 %, cornell_smoke -9 %).
+        const bool first_two = first_is_scan && !readback && depth >= 2 && tail_from >= 2 && (RT_SCAN_TWO == 2 || (RT_SCAN_TWO == 1 && sc->n_long_leaves == 0));
         const bool calibrating = !fixed && tail_from < 0 && !profile;  // this pass also times its kernels, to see whether splitting later passes pays
         L.profile = profile || calibrating;
         const int n_halves = (!fixed && !readback && split_pays && ns >= RT_PASS_PARTS && !(ro->flags & RT_RENDER_ONE_STREAM)) ? RT_PASS_PARTS : 1;
@@ -1367,6 +1390,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         }
         sc->prof.passes += 1;
         sc->prof.two_stream_passes += n_halves > 1 ? 1u : 0u;
+        sc->prof.two_bounce_passes += first_two ? 1u : 0u;
         // The first sizeable pass on a scene handle lends some of its rays to the regrouping of the tree (tune_tree).
         const bool sampling = !fixed && !sc->tree_tuned && !(ro->flags & RT_RENDER_KEEP_TREE) && !fused && sc->n_leaves > RT_SCAN_MAX_LEAVES &&
                               half[0].P.n_paths >= RT_TUNE_MIN_PATHS;
@@ -1375,6 +1399,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         bool finished = false;
         for (; b < depth; ++b) {
             if (tail_from >= 0 && !force_wavefront && (int)b >= tail_from) break;
+            const bool two = b == 0 && first_two;  // this launch runs bounces 0 and 1
             for (int k = 0; k < n_halves; ++k) {  // (event timing only in one-half passes: L works on `stream`)
                 Half& h = half[k];
                 if (sampling && k == 0 && b < RT_TUNE_BOUNCES) {
@@ -1389,8 +1414,8 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 }
                 if (n_halves == 1 && (st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
                 if (fused && scan)
-                    hipLaunchKernelGGL(b == 0 && first_is_scan ? shade_scan_first : shade_scan, dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes, h.stream, sc->view, h.P,
-                                       h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + 1, h.values, b);
+                    hipLaunchKernelGGL(two ? shade_scan_first_two : (b == 0 && first_is_scan ? shade_scan_first : shade_scan), dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes,
+                                       h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + (two ? 2 : 1), h.values, b);
                 else if (fused)
                     hipLaunchKernelGGL(shade_walk, dim3(shade_grid[k]), dim3(RT_SHADE_BS), lds_bytes, h.stream, sc->view, h.P,
                                        h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + 1, h.values, b);
@@ -1401,6 +1426,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                 h.cur ^= 1;
             }
             HIP_TRY(hipGetLastError());
+            if (two) ++b;
             if (readback) {
                 HIP_TRY(hipMemcpyAsync(sc->h_counts, half[0].counts + b, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipMemcpyAsync(sc->h_counts + 2, half[0].counts + n_counts + b, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

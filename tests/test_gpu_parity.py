@@ -360,6 +360,26 @@ def test_result_does_not_depend_on_passes_kernel_split_or_ranks(earth):
         assert not np.array_equal(other, base)
 
 
+def test_two_bounces_in_the_first_launch_change_no_byte(earth):
+    """Scenes of a few leaves without long-test leaves (perlin) run bounces 0 and 1 of a pass in one launch once the schedule is
+    known (rt_profile.two_bounce_passes); passes that read queue lengths back never do.  Same bytes either way, also when the
+    second bounce is the last one allowed (max_reflections 2) and when there is only one (1)."""
+    sc, co = _example("perlin", earth)
+    cam = rt.Camera(co)
+    for depth, expect in ((50, 3), (3, 3), (2, 3), (1, 0)):
+        io = rt.ImageOptions(144, 256, 64, depth)
+        _, got = sc.render(cam, io, rt.RenderOptions(seed=9, samples_per_pass=16), want_mean=True)   # 4 passes of 590 k paths: the first learns the schedule
+        prof = sc.profile()
+        assert prof["passes"] == 4 and prof["two_bounce_passes"] == expect, (depth, prof)
+        _, ref = sc.render(cam, io, rt.RenderOptions(seed=9, samples_per_pass=16, flags=_abi.RT_RENDER_NO_TAIL), want_mean=True)
+        assert sc.profile()["two_bounce_passes"] == 0
+        assert np.array_equal(got, ref) and ref.any(), depth
+    # the queue of the Cornell rooms is ordered by long-test leaves: one bounce per launch
+    sc, co = _example("cornell", earth)
+    sc.render(rt.Camera(co), rt.ImageOptions(144, 256, 64, 50), rt.RenderOptions(seed=9, samples_per_pass=16))
+    assert sc.profile()["passes"] == 4 and sc.profile()["two_bounce_passes"] == 0
+
+
 def test_pixels_entry_point_matches_rt_render(earth):
     """`pixels(&camera, &scene, image_options)` through the C++ host entry: same bytes as rt_render, row-major, top row first."""
     sc, co = _example("cornell", earth)

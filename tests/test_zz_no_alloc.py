@@ -36,6 +36,10 @@ def test_noalloc_render_matches_render_device(earth):
     sm, cs = rt.Scene.example("cornell_smoke", 1)
     ref, got = _both(sm, rt.Camera(cs), rt.ImageOptions(64, 64, 9, 50), 5, rank=1, world_size=3, tile_w=8, tile_h=4)
     assert np.array_equal(got, ref) and ref.any()
+    # a scene whose first launch of a pass runs two bounces (the static workspace's schedule is fixed: nothing is read back)
+    pl, cp = rt.Scene.example("perlin", 1)
+    ref, got = _both(pl, rt.Camera(cp), rt.ImageOptions(120, 160, 40, 50), 6)
+    assert np.array_equal(got, ref) and ref.any() and pl.profile()["two_bounce_passes"] == 4
 
 
 def test_noalloc_render_takes_no_device_memory(earth):
