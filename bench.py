@@ -339,6 +339,7 @@ def main(argv=None):
                             "bytes_per_segment": round(bytes_per_seg, 1), "flops_per_segment": round(flops_per_seg, 1), "ms_per_launch": round(ms_per_launch, 4),
                             "counters": pmc}
                 if fused:
+                    # (the profiled launches are one bounce each; in the timed frame the first launch of a pass may run two, see schedule)
                     roofline["note"] = ("under neither roof: the kernel's waves wait on their own dependent loads (counters.wait_share) with the vector "
                                         "units counters.valu_busy busy; frac is the HBM fraction, valu_frac the fp32 vector fraction of the same launches")
             roofline.update(common)
@@ -351,7 +352,7 @@ def main(argv=None):
                              "backend": (dist.get_backend() if grouped else None)},
                   "ranks": ranks, "distinct_gpus": len({(r["host"], r["pci_bus_id"]) for r in ranks}),
                   "schedule": {"pass_paths": schedule["pass_paths"], "tail_from": schedule["tail_from"], "two_stream_passes": schedule["two_stream_passes"],
-                               "passes": schedule["passes"]},
+                               "passes": schedule["passes"], "two_bounce_passes": schedule["two_bounce_passes"]},
                   "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(result), flush=True)
         if store is not None:
