@@ -717,6 +717,7 @@ struct Ray {
 #define RT_NODE_LEAF 0x10000000u
 #define RT_NODE_PLAIN_BOX 0x40000000u
 #define RT_NODE_PLAIN_SPHERE 0x20000000u
+#define RT_NODE_MOVING_SPHERE (RT_NODE_PLAIN_SPHERE | RT_NODE_PLAIN_RECT)  // (a sphere leaf is no rectangle: the two bits together mark an unwrapped MovingSphere)
 
 // A node's box is held as centre and half-widths: the two plane parameters of an axis are then
 //   (c * inv - o * inv) -+ h * |inv|,   near first whatever the sign of the direction,
@@ -927,6 +928,11 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
         const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
         return Pp.geom == RT_GEOM_SPHERE && !(Pp.flags & (RT_PRIM_MEDIUM | RT_PRIM_BOTH_ROOTS));  // (the far-root variant takes the general test)
     };
+    auto moving_sphere = [&](const rt_bvh_node& N) {  // (unwrapped: a wrapped one takes the general test)
+        if (N.prim == RT_BVH_NONE) return false;
+        const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
+        return Pp.geom == RT_GEOM_MOVING_SPHERE && Pp.xf_count == 0 && !(Pp.flags & (RT_PRIM_MEDIUM | RT_PRIM_BOTH_ROOTS));
+    };
     auto plain_box = [&](const rt_bvh_node& N) {  // exact leaf of an unwrapped box whose box is the leaf's box (rounded to fp32)
         if (N.prim == RT_BVH_NONE || !(N.prim & RT_BVH_EXACT)) return false;
         const rt_prim& Pp = D->prims[N.prim & RT_NODE_PRIM_MASK];
@@ -942,7 +948,7 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
         return Pp.geom == RT_GEOM_RECT && Pp.xf_count == 0 && !(Pp.flags & RT_PRIM_MEDIUM);
     };
     auto exact_leaf = [&](const rt_bvh_node& N) { return N.prim != RT_BVH_NONE && ((N.prim & RT_BVH_EXACT) != 0 || plain_rect(N)); };
-    auto payload_slots = [&](const rt_bvh_node& N) { return plain_sphere(N) ? 1u : ((plain_box(N) || plain_rect(N)) ? 2u : (exact_leaf(N) ? 1u : 0u)); };
+    auto payload_slots = [&](const rt_bvh_node& N) { return plain_sphere(N) ? 1u : ((moving_sphere(N) || plain_box(N) || plain_rect(N)) ? 2u : (exact_leaf(N) ? 1u : 0u)); };
     // exact leaves keep their exact box in a payload slot; the box in the node itself, which only decides whether the walk
     // visits the leaf, is widened like every other node box (the fp32 slab test is accurate to ulps of origin / direction)
     double max_abs = 0.0;
@@ -974,6 +980,13 @@ inline void make_walk_nodes(const rt_scene_desc* D, std::vector<WalkNode>& nodes
                 }
                 const double payload[4] = {c.x, c.y, c.z, sp.radius};
                 static_assert(sizeof(payload) == sizeof(WalkNode), "payload slot size");
+                std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
+            } else if (moving_sphere(N)) {
+                // centre at the start time and radius as a plain sphere's, then the motion per unit of time and the start time
+                W.prim |= RT_NODE_MOVING_SPHERE;
+                const rt_sphere& sp = D->spheres[Pp.geom_index];
+                const double payload[8] = {sp.center[0], sp.center[1], sp.center[2], sp.radius, sp.motion[0], sp.motion[1], sp.motion[2], sp.start_time};
+                static_assert(sizeof(payload) == 2 * sizeof(WalkNode), "payload slot size");
                 std::memcpy(&nodes[new_index[i] + 1], payload, sizeof(payload));
             } else if (plain_rect(N)) {
                 // Shape::bound of a Rectangle (shape.rs:457-481): its extents, and the plane padded by 0.0001 on its axis
@@ -1101,8 +1114,10 @@ RT_HD bool walk_leaf_fast(const SceneView& S, const Ray& r, V3 inv_capped, float
         const double* c = reinterpret_cast<const double*>(&node_at(S.bvh, w.leaf_node + RT_NODE_STRIDE));
         rt_sphere sp;
         sp.center[0] = c[0]; sp.center[1] = c[1]; sp.center[2] = c[2]; sp.radius = c[3];
+        const bool moving = (leaf & RT_NODE_PLAIN_RECT) != 0u;  // RT_NODE_MOVING_SPHERE: the second payload slot holds motion and start time; needs r.time
+        if (moving) { sp.motion[0] = c[4]; sp.motion[1] = c[5]; sp.motion[2] = c[6]; sp.start_time = c[7]; }
         double t64;
-        if (sphere_root(sp, false, d3(r.o), d3(r.d), r.time, t64) && t64 > (double)tmin && t64 < (double)w.tmax) walk_accept(w, (float)t64, prim, 0);
+        if (sphere_root(sp, moving, d3(r.o), d3(r.d), r.time, t64) && t64 > (double)tmin && t64 < (double)w.tmax) walk_accept(w, (float)t64, prim, 0);
         return true;
     }
     if (!(leaf & RT_BVH_EXACT)) return false;
@@ -1150,6 +1165,9 @@ RT_HD void walk_leaf_generic(const SceneView& S, const Ray& r, float tmin, const
 // The whole walk for one ray.  Two nested loops on purpose: the inner loop only steps over nodes until it
 // stands on a leaf, the outer loop runs the (much longer) primitive test, so the lanes of a wave run their
 // primitive tests together, once per round.
+// GENERIC = false: for trees none of whose leaves takes the general test (the caller has checked); the kernels built that way
+// need far fewer registers.
+template <bool GENERIC = true>
 RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax, const DrawKey& key, float& best_t, uint32_t& best_prim, int& best_side) {
     if (has_negative_zero(r.d)) return false;
     const V3 inv_c = walk_cap(ray_inv(r.d));
@@ -1160,7 +1178,7 @@ RT_HD bool closest_hit(const SceneView& S, const Ray& r, float tmin, float tmax,
         uint32_t leaf = RT_BVH_NONE;
         while (w.i < n && leaf == RT_BVH_NONE) leaf = walk_step(S, inv_c, oi, tmin, w);
         if (leaf == RT_BVH_NONE) break;
-        if (!walk_leaf_fast(S, r, inv_c, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, key, leaf, w);
+        if (!walk_leaf_fast(S, r, inv_c, tmin, leaf, w) && GENERIC) walk_leaf_generic(S, r, tmin, key, leaf, w);
     }
     best_t = w.t; best_prim = w.prim; best_side = w.side;
     return w.found;

@@ -240,7 +240,9 @@ __device__ unsigned long long g_trav_stats[16];
 #else
 #define RT_STAT(k, v)
 #endif
-template <bool NODES_IN_LDS, bool MULTI = false>
+// GENERIC = false: no leaf of the tree takes the general primitive test (the host has looked); without that code the kernel needs
+// 54 registers instead of its 80 with 8 spilled.
+template <bool NODES_IN_LDS, bool MULTI = false, bool GENERIC = true>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LDS ? 6 : 1) k_traverse(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr,
                                                                                    uint2* hits, uint32_t bounce) {
     extern __shared__ uint4 lds_nodes[];
@@ -347,7 +349,9 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS, NODES_IN_LD
                 if (has && ((leaf & RT_NODE_PLAIN_SPHERE) != 0u) == (round == 0)) {
                     Walk w; walk_init(w, t_end);
                     w.leaf_node = p0;
-                    if (!walk_leaf_fast(S, r, inv, tmin, leaf, w)) {  // only these leaves need the ray's time (moving spheres) and the path and pixel numbers (they key a medium's draw)
+                    // (the ray's time is not loaded with the ray: only a moving sphere needs it)
+                    if (round == 0 && (leaf & RT_NODE_PLAIN_RECT) != 0u) r.time = q.od1[slot].z;
+                    if (!walk_leaf_fast(S, r, inv, tmin, leaf, w) && GENERIC) {  // these leaves also need the path and pixel numbers (they key a medium's draw)
                         const float4 b = q.od1[slot];
                         r.time = b.z;
                         walk_leaf_generic(S, r, tmin, make_key(P, __float_as_uint(b.w), __float_as_uint(q.thr[slot].w), bounce), leaf, w);
@@ -406,6 +410,7 @@ enum { SHADE_HITS = 0, SHADE_WALK = 1, SHADE_SCAN = 2 };
 // bounds as in closest_hit().  The kind of the leaf is the same for all lanes, so its test is straight code for the wave
 // instead of each lane's own branch, and a scene of eight objects costs eight box tests and the tests of the leaves some lane
 // enters, not a persistent kernel's turns.  `live`: lanes without a ray go through the motions with every test masked off.
+template <bool GENERIC>
 __device__ __forceinline__ bool closest_hit_scan(const SceneView& S, const Ray& r, bool live, float tmin, const DrawKey& key, float& best_t, uint32_t& best_prim,
                                                  int& best_side) {
     const bool ok = live && !has_negative_zero(r.d);
@@ -421,7 +426,7 @@ __device__ __forceinline__ bool closest_hit_scan(const SceneView& S, const Ray& 
         const bool pass = ok && node_hit(N, inv_c, oi, tmin, fminf(w.tmax, RT_WALK_FAR));
         if (__ballot(pass) != 0ull && pass) {
             w.leaf_node = pos;
-            if (!walk_leaf_fast(S, r, inv_c, tmin, leaf, w)) walk_leaf_generic(S, r, tmin, key, leaf, w);
+            if (!walk_leaf_fast(S, r, inv_c, tmin, leaf, w) && GENERIC) walk_leaf_generic(S, r, tmin, key, leaf, w);
         }
         pos = skip;  // a leaf's skip link also jumps over its payload slots
     }
@@ -515,7 +520,7 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (TWO ? RT
             for (uint32_t k = 0; k < (TWO ? 2u : 1u); ++k) {
                 key.bounce = bounce + k;
                 float t = 0.0f; uint32_t prim = 0; int side = 0;
-                const bool hit = closest_hit_scan(S, r, alive, 0.001f, key, t, prim, side);  // lib.rs:90: (0.001, inf)
+                const bool hit = closest_hit_scan<LONG_LEAVES>(S, r, alive, 0.001f, key, t, prim, side);  // lib.rs:90: (0.001, inf); without long-test leaves no leaf takes the general test
                 if (alive) {
                     V3 value;
                     alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + k + 1 >= P.max_depth, value);
@@ -590,7 +595,7 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (TWO ? RT
 }
 
 // Every ray left in the queue runs the remaining iterations of ray_color in one launch.
-template <bool NODES_IN_LDS, bool SIDES>
+template <bool NODES_IN_LDS, bool SIDES, bool GENERIC = true>
 __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_tail(SceneView S0, PassParams P, RayQueue q, const uint32_t* count_ptr, float4* values, uint32_t* segment_counter,
                                                      uint32_t first_bounce) {
     extern __shared__ uint4 lds_nodes[];
@@ -609,7 +614,7 @@ __global__ void __launch_bounds__(NODES_IN_LDS ? RT_TRAV_BS : RT_BS) k_tail(Scen
             key.bounce = bounce;
             ++segments;
             float t = 0.0f; uint32_t prim = 0; int side = 0;
-            bool hit = closest_hit(S, r, 0.001f, RT_INF_F, key, t, prim, side);
+            bool hit = closest_hit<GENERIC>(S, r, 0.001f, RT_INF_F, key, t, prim, side);
             if (!shade_step(S, r, thr, key, hit, t, prim, side, bounce + 1 >= P.max_depth, value)) break;
         }
         values[path] = make_float4(value.x, value.y, value.z, 0.0f);
@@ -1025,12 +1030,14 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
     }
     if (sc->nodes_fit_lds) {
         hipFuncAttributes fa;
-        for (const void* f : {reinterpret_cast<const void*>(&k_traverse<true, false>), reinterpret_cast<const void*>(&k_traverse<true, true>)}) {
+        for (const void* f : {reinterpret_cast<const void*>(&k_traverse<true, false>), reinterpret_cast<const void*>(&k_traverse<true, true>),
+                              reinterpret_cast<const void*>(&k_traverse<true, false, false>)}) {
             if (e == hipSuccess) e = hipFuncGetAttributes(&fa, f);
             if (e == hipSuccess && fa.sharedSizeBytes != 0) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, "k_traverse has static LDS in front of its node array"); }
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         }
         const void* const walkers[] = {reinterpret_cast<const void*>(&k_tail<true, false>), reinterpret_cast<const void*>(&k_tail<true, true>),
+                                       reinterpret_cast<const void*>(&k_tail<true, false, false>), reinterpret_cast<const void*>(&k_tail<true, true, false>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_WALK, false>), reinterpret_cast<const void*>(&k_shade<SHADE_WALK, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true>),
@@ -1316,10 +1323,11 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     };
     const bool sides = sc->view.side_rounding != 0u;  // (which build of the shading kernels: see stage_nodes)
     const bool multi = sc->view.multi_scatter != 0u;  // (which build of the traversal kernel: see stage_nodes)
-    const auto traverse_lds = multi ? &k_traverse<true, true> : &k_traverse<true, false>;
-    const auto traverse_global = multi ? &k_traverse<false, true> : &k_traverse<false, false>;
-    const auto tail_lds = sides ? &k_tail<true, true> : &k_tail<true, false>;
-    const auto tail_global = sides ? &k_tail<false, true> : &k_tail<false, false>;
+    const bool generic = sc->n_long_leaves != 0;       // (some leaf takes the general primitive test: the builds with that code)
+    const auto traverse_lds = !generic ? &k_traverse<true, false, false> : (multi ? &k_traverse<true, true> : &k_traverse<true, false>);
+    const auto traverse_global = !generic ? &k_traverse<false, false, false> : (multi ? &k_traverse<false, true> : &k_traverse<false, false>);
+    const auto tail_lds = generic ? (sides ? &k_tail<true, true> : &k_tail<true, false>) : (sides ? &k_tail<true, true, false> : &k_tail<true, false, false>);
+    const auto tail_global = generic ? (sides ? &k_tail<false, true> : &k_tail<false, false>) : (sides ? &k_tail<false, true, false> : &k_tail<false, false, false>);
     const auto shade_scan = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true> : &k_shade<SHADE_SCAN, false, true>)
                                               : (sides ? &k_shade<SHADE_SCAN, true, false> : &k_shade<SHADE_SCAN, false, false>);
     const auto shade_scan_first = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true, true> : &k_shade<SHADE_SCAN, false, true, true>)

@@ -400,15 +400,21 @@ def test_walk_node_array_keeps_the_reference_leaf_order(earth):
                 leaves.append(int(prim[i] & PRIM_MASK))
                 P = d.prims[leaves[-1]]
                 if prim[i] & PLAIN_SPHERE:
-                    assert P.geom == _abi.RT_GEOM_SPHERE and not (P.flags & _abi.RT_PRIM_MEDIUM)
+                    moving = bool(prim[i] & PLAIN_RECT)                      # (the two bits together: an unwrapped MovingSphere, two payload slots)
+                    assert P.geom == (_abi.RT_GEOM_MOVING_SPHERE if moving else _abi.RT_GEOM_SPHERE) and not (P.flags & _abi.RT_PRIM_MEDIUM)
                     is_payload[i + 1] = True
                     c = raw[i + 1].view(np.float64)
                     sp = d.spheres[P.geom_index]
                     assert c[3] == sp.radius
                     if P.xf_count == 0:
                         assert list(c[:3]) == list(sp.center)
-                    assert skip[i] == i + 2
-                    i += 1
+                    if moving:
+                        assert P.xf_count == 0
+                        is_payload[i + 2] = True
+                        m = raw[i + 2].view(np.float64)
+                        assert list(m[:3]) == list(sp.motion) and m[3] == sp.start_time
+                    assert skip[i] == i + (3 if moving else 2)
+                    i += 2 if moving else 1
                 elif prim[i] & _abi.RT_BVH_EXACT:
                     # exact leaves: the exact box in the next slot, inside the (widened) box of the node itself
                     is_payload[i + 1] = True
