@@ -464,12 +464,18 @@ __device__ __forceinline__ bool scan_queue_end(const SceneView& S, const Ray& r)
 #ifndef RT_SCAN_GRID_PER_CU
 #define RT_SCAN_GRID_PER_CU 8u  // workgroups of a scanned bounce per CU (four are resident at a time)
 #endif
+#ifndef RT_PLAIN_SCAN_GRID_PER_CU
+#define RT_PLAIN_SCAN_GRID_PER_CU 15u  // ... of the builds without long-test leaves (five resident)
+#endif
 __host__ __device__ constexpr uint32_t shade_bs(int mode) { return mode == 2 /* SHADE_SCAN */ ? 256u : RT_SHADE_BS; }
 #ifndef RT_TWO_WAVES
-#define RT_TWO_WAVES 4
+#define RT_TWO_WAVES 5
+#endif
+#ifndef RT_PLAIN_SCAN_WAVES
+#define RT_PLAIN_SCAN_WAVES 5
 #endif
 template <int MODE, bool SIDES, bool LONG_LEAVES = false, bool FIRST = false, bool TWO = false>
-__global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (TWO ? RT_TWO_WAVES : 4) : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+__global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (MODE == SHADE_SCAN && !LONG_LEAVES ? (TWO ? RT_TWO_WAVES : RT_PLAIN_SCAN_WAVES) : 4) : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
     constexpr uint32_t BS = shade_bs(MODE);
     extern __shared__ uint4 lds_nodes[];
@@ -1388,7 +1394,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
             const uint32_t grid_full = (h.P.n_paths + RT_BS - 1) / RT_BS;
             grid[k] = std::min(grid_full, max_grid);
             shade_grid[k] = std::min((h.P.n_paths + RT_SHADE_BS - 1) / RT_SHADE_BS, max_grid * RT_BS / RT_SHADE_BS);
-            scan_grid[k] = std::min((h.P.n_paths + shade_bs(SHADE_SCAN) - 1) / shade_bs(SHADE_SCAN), sc->n_cu * RT_SCAN_GRID_PER_CU);
+            scan_grid[k] = std::min((h.P.n_paths + shade_bs(SHADE_SCAN) - 1) / shade_bs(SHADE_SCAN), sc->n_cu * (sc->n_long_leaves ? RT_SCAN_GRID_PER_CU : RT_PLAIN_SCAN_GRID_PER_CU));
             trav_grid[k] = std::min((h.P.n_paths + RT_TRAV_BS - 1) / RT_TRAV_BS, sc->n_cu);
             if (k == 0 && (st = L.begin(RT_K_RAYGEN, &ev)) != RT_OK) return st;
             if (first_is_scan) hipLaunchKernelGGL(k_reset_counts, dim3(1), dim3(64), 0, h.stream, h.counts, n_counts, h.P.n_paths);
