@@ -381,14 +381,14 @@ __device__ unsigned long long g_shade_stats[40];
 // Workgroup size of k_shade.  Each workgroup pass ends in one atomic on the length of the next queue; at 256 threads
 // the rate of those atomics (all on one address) bounds the kernel, at 512 it runs within a few per cent of the same
 // kernel without compaction, which moves its ~100 bytes per segment at over half of the HBM peak.
-// Register budgets: k_traverse is held to 80 VGPRs (4 waves per SIMD = 320 of the 512 registers of a lane) and k_shade
-// to 96, so that one shading workgroup (2 waves per SIMD) fits beside the traversal workgroup of the pass's other half.
+// Register budgets: k_traverse is held to 80 VGPRs (4 waves per SIMD = 320 of the 512 registers of a lane; its build without the
+// general primitive test takes 52) and k_shade to 96, so that one shading workgroup (2 waves per SIMD) fits beside the traversal workgroup of the pass's other half.
 #define RT_SHADE_BS 512
 #ifndef RT_SHADE_PRIO
 #define RT_SHADE_PRIO 3
 #endif
 #ifndef RT_SCAN_TWO
-#define RT_SCAN_TWO 1  // the first launch of a scanned pass runs two bounces: 0 never, 1 in scenes without long-test leaves, 2 always
+#define RT_SCAN_TWO 1  // the first launch of a scanned pass runs two bounces in scenes without long-test leaves
 #endif
 #ifndef RT_SCAN_FIRST
 #define RT_SCAN_FIRST 1
@@ -464,6 +464,9 @@ __device__ __forceinline__ bool scan_queue_end(const SceneView& S, const Ray& r)
 #ifndef RT_SCAN_GRID_PER_CU
 #define RT_SCAN_GRID_PER_CU 8u  // workgroups of a scanned bounce per CU (four are resident at a time)
 #endif
+#ifndef RT_SCAN_SPLIT
+#define RT_SCAN_SPLIT 1  // scanned bounces of a queue ordered by long-test leaves run as two launches (front, back)
+#endif
 #ifndef RT_PLAIN_SCAN_GRID_PER_CU
 #define RT_PLAIN_SCAN_GRID_PER_CU 15u  // ... of the builds without long-test leaves (five resident)
 #endif
@@ -474,8 +477,20 @@ __host__ __device__ constexpr uint32_t shade_bs(int mode) { return mode == 2 /* 
 #ifndef RT_PLAIN_SCAN_WAVES
 #define RT_PLAIN_SCAN_WAVES 5
 #endif
-template <int MODE, bool SIDES, bool LONG_LEAVES = false, bool FIRST = false, bool TWO = false>
-__global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (MODE == SHADE_SCAN && !LONG_LEAVES ? (TWO ? RT_TWO_WAVES : RT_PLAIN_SCAN_WAVES) : 4) : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
+#ifndef RT_FRONT_SCAN_WAVES
+#define RT_FRONT_SCAN_WAVES 5
+#endif
+#ifndef RT_LONG_FIRST_WAVES
+#define RT_LONG_FIRST_WAVES 4
+#endif
+#ifndef RT_BACK_SCAN_WAVES
+#define RT_BACK_SCAN_WAVES 5
+#endif
+// PART (scanned bounces of scenes with long-test leaves, whose queue is ordered by them): 0 = the whole queue, 1 = its front part,
+// 2 = its back part, whose rays pass every long-test leaf by (scan_queue_end said so with the scan's own box test), in a build
+// without the general primitive test.
+template <int MODE, bool SIDES, bool LONG_LEAVES = false, bool FIRST = false, bool TWO = false, int PART = 0>
+__global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (MODE == SHADE_SCAN && !LONG_LEAVES ? (TWO ? RT_TWO_WAVES : RT_PLAIN_SCAN_WAVES) : (PART == 2 ? RT_BACK_SCAN_WAVES : (PART == 1 ? RT_FRONT_SCAN_WAVES : (MODE == SHADE_SCAN && FIRST ? RT_LONG_FIRST_WAVES : 4)))) : 5) k_shade(SceneView S0, PassParams P, RayQueue qin, const uint2* hits, RayQueue qout, const uint32_t* count_ptr,
                                                  uint32_t* next_count, float4* values, uint32_t bounce) {
     constexpr uint32_t BS = shade_bs(MODE);
     extern __shared__ uint4 lds_nodes[];
@@ -492,7 +507,8 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (MODE == 
     // written (96 bytes per path less through memory; perlin's paths are 2.3 segments long)
     const uint32_t n_front = FIRST ? P.n_paths : count_ptr[0], count = FIRST ? P.n_paths : n_front + count_ptr[P.n_counts];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * BS; base < count; base += gridDim.x * BS) {
+    const uint32_t lo = PART == 2 ? n_front : 0u, hi = PART == 1 ? n_front : count;
+    for (uint32_t base = lo + blockIdx.x * BS; base < hi; base += gridDim.x * BS) {
         const uint32_t i = base + threadIdx.x;
         bool alive = false, to_front = false;
         Ray r; V3 thr; uint32_t path = 0, pixel = 0;
@@ -500,7 +516,7 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (MODE == 
             // the scan is the wave's, so the hit is found outside the per-lane branch below
             DrawKey key = make_key(P, 0u, 0u, bounce);
             r.o = v3(0.0f, 0.0f, 0.0f); r.d = v3(1.0f, 1.0f, 1.0f); r.time = 0.0f; thr = v3(0.0f, 0.0f, 0.0f);
-            const bool live = i < count;
+            const bool live = i < hi;
             if (live && FIRST) {  // (as k_raygen)
                 path = i;
                 const uint32_t sample = path_sample(P, path);
@@ -526,7 +542,7 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (MODE == 
             for (uint32_t k = 0; k < (TWO ? 2u : 1u); ++k) {
                 key.bounce = bounce + k;
                 float t = 0.0f; uint32_t prim = 0; int side = 0;
-                const bool hit = closest_hit_scan<LONG_LEAVES>(S, r, alive, 0.001f, key, t, prim, side);  // lib.rs:90: (0.001, inf); without long-test leaves no leaf takes the general test
+                const bool hit = closest_hit_scan<LONG_LEAVES && PART != 2>(S, r, alive, 0.001f, key, t, prim, side);  // lib.rs:90: (0.001, inf); without long-test leaves no leaf takes the general test
                 if (alive) {
                     V3 value;
                     alive = shade_step(S, r, thr, key, hit, t, prim, side, bounce + k + 1 >= P.max_depth, value);
@@ -535,7 +551,7 @@ __global__ void __launch_bounds__(shade_bs(MODE), MODE != SHADE_HITS ? (MODE == 
             }
             if (alive && !LONG_LEAVES) to_front = (P.up_axis == 1 ? r.d.y : (P.up_axis == 0 ? r.d.x : r.d.z)) * P.up_sign > 0.0f;
             if (LONG_LEAVES) to_front = alive && scan_queue_end(S, r);
-        } else if (i < count) {
+        } else if (i < hi) {
             const uint32_t at = queue_slot(i, n_front, P.n_paths);
             const NtF4 a_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od0[at])), b_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.od1[at])),
                        c_ = __builtin_nontemporal_load(reinterpret_cast<const NtF4*>(&qin.thr[at]));
@@ -1050,7 +1066,9 @@ rt_status rt_scene_create(const rt_scene_desc* D, int device, rt_scene** out) {
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, false, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, false, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, true>),
                                        reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, false, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, false, true, true>),
-                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, true, true>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, true, true>)};
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, false, false, 1>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, false, false, 1>),
+                                       reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, false, true, false, false, 2>), reinterpret_cast<const void*>(&k_shade<SHADE_SCAN, true, true, false, false, 2>),
+                                       };
         for (const void* f : walkers) if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_NODE_LIMIT);
         if (e != hipSuccess) { rt_scene_destroy(sc); return fail(RT_ERR_HIP, std::string("LDS set-up of the walk kernels: ") + hipGetErrorString(e)); }
     }
@@ -1338,8 +1356,9 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                                               : (sides ? &k_shade<SHADE_SCAN, true, false> : &k_shade<SHADE_SCAN, false, false>);
     const auto shade_scan_first = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true, true> : &k_shade<SHADE_SCAN, false, true, true>)
                                                     : (sides ? &k_shade<SHADE_SCAN, true, false, true> : &k_shade<SHADE_SCAN, false, false, true>);
-    const auto shade_scan_first_two = sc->n_long_leaves ? (sides ? &k_shade<SHADE_SCAN, true, true, true, true> : &k_shade<SHADE_SCAN, false, true, true, true>)
-                                                        : (sides ? &k_shade<SHADE_SCAN, true, false, true, true> : &k_shade<SHADE_SCAN, false, false, true, true>);
+    const auto shade_scan_first_two = sides ? &k_shade<SHADE_SCAN, true, false, true, true> : &k_shade<SHADE_SCAN, false, false, true, true>;  // (scenes without long-test leaves only)
+    const auto shade_scan_front = sides ? &k_shade<SHADE_SCAN, true, true, false, false, 1> : &k_shade<SHADE_SCAN, false, true, false, false, 1>;
+    const auto shade_scan_back = sides ? &k_shade<SHADE_SCAN, true, true, false, false, 2> : &k_shade<SHADE_SCAN, false, true, false, false, 2>;
     const auto shade_walk = sides ? &k_shade<SHADE_WALK, true> : &k_shade<SHADE_WALK, false>;
     const auto shade_hits = sides ? &k_shade<SHADE_HITS, true> : &k_shade<SHADE_HITS, false>;
     auto launch_traverse = [&](Half& h, uint32_t b, uint32_t grid, uint32_t trav_grid) {
@@ -1368,7 +1387,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
         // every path has a second segment, so the lanes stay full, and 96 bytes per path stay out of memory (perlin, whose
         // paths are 2.3 segments long: 10 890 -> 11 950 Msamples/s).  Not where the queue is ordered by long-test leaves: the
         // second bounce would run unordered (cornell -2 %, cornell_smoke -9 %).
-        const bool first_two = first_is_scan && !readback && depth >= 2 && tail_from >= 2 && (RT_SCAN_TWO == 2 || (RT_SCAN_TWO == 1 && sc->n_long_leaves == 0));
+        const bool first_two = RT_SCAN_TWO && first_is_scan && !readback && depth >= 2 && tail_from >= 2 && sc->n_long_leaves == 0;
         const bool calibrating = !fixed && tail_from < 0 && !profile;  // this pass also times its kernels, to see whether splitting later passes pays
         L.profile = profile || calibrating;
         const int n_halves = (!fixed && !readback && split_pays && ns >= RT_PASS_PARTS && !(ro->flags & RT_RENDER_ONE_STREAM)) ? RT_PASS_PARTS : 1;
@@ -1427,7 +1446,13 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
                     if (n_halves == 1 && (st = L.end(ev)) != RT_OK) return st;
                 }
                 if (n_halves == 1 && (st = L.begin(RT_K_SHADE, &ev)) != RT_OK) return st;
-                if (fused && scan)
+                if (fused && scan && RT_SCAN_SPLIT && sc->n_long_leaves && !(b == 0 && first_is_scan)) {
+                    // the queue is ordered by long-test leaves: its back part runs the build without the general test
+                    hipLaunchKernelGGL(shade_scan_front, dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
+                                       h.counts + b, h.counts + b + 1, h.values, b);
+                    hipLaunchKernelGGL(shade_scan_back, dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes, h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1],
+                                       h.counts + b, h.counts + b + 1, h.values, b);
+                } else if (fused && scan)
                     hipLaunchKernelGGL(two ? shade_scan_first_two : (b == 0 && first_is_scan ? shade_scan_first : shade_scan), dim3(scan_grid[k]), dim3(shade_bs(SHADE_SCAN)), lds_bytes,
                                        h.stream, sc->view, h.P, h.q[h.cur], h.hits, h.q[h.cur ^ 1], h.counts + b, h.counts + b + (two ? 2 : 1), h.values, b);
                 else if (fused)
