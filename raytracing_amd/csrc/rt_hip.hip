@@ -464,6 +464,9 @@ __device__ __forceinline__ bool scan_queue_end(const SceneView& S, const Ray& r)
 #ifndef RT_SCAN_GRID_PER_CU
 #define RT_SCAN_GRID_PER_CU 8u  // workgroups of a scanned bounce per CU (four are resident at a time)
 #endif
+#ifndef RT_TAIL_PER_CU
+#define RT_TAIL_PER_CU 512u  // rays per CU at which the queue is short enough for k_tail to take the rest of every path
+#endif
 #ifndef RT_SCAN_SPLIT
 #define RT_SCAN_SPLIT 1  // scanned bounces of a queue ordered by long-test leaves run as two launches (front, back)
 #endif
@@ -1308,7 +1311,7 @@ static rt_status render_impl(rt_scene* sc, const rt_camera* cam, const rt_image_
     size_t node_bytes = ((size_t)sc->view.n_bvh_nodes + 1) * sizeof(WalkNode);
     const bool nodes_in_lds = sc->nodes_fit_lds && !(ro->flags & RT_RENDER_NODES_IN_GLOBAL);
     size_t lds_bytes = node_bytes + RT_LDS_BEHIND_NODES + sc->view.lds_scene_bytes;  // dynamic LDS of the kernels that stage the nodes (changes when the tree is regrouped)
-    const uint32_t tail_threshold = sc->n_cu * 512u;
+    const uint32_t tail_threshold = sc->n_cu * RT_TAIL_PER_CU;
     Launcher L{sc, stream, profile};
     hipEvent_t ev;
 
