@@ -55,7 +55,7 @@ def test_converged_image_matches_the_oracle(name, earth):
     sc, co = rt.Scene.example(name, int(fx["scene_seed"]), earth if name == "final_scene" else None)
     _, mean = sc.render(rt.Camera(co), rt.ImageOptions(h, w, spp, depth), rt.RenderOptions(seed=SEED_GPU), want_mean=True)
     assert SEED_GPU not in (int(fx["seed_a"]), int(fx["seed_b"]))
-    st = converged_stats(mean, fx["mean_a"], fx["mean_b"])
+    st = converged_stats(mean, fx["mean_a"].astype(np.float64), fx["mean_b"].astype(np.float64))
     print(f"\n{name} {w}x{h} {spp} spp: RMSE(gpu, A) {np.round(st['err'], 3)} vs floor RMSE(A, B) {np.round(st['floor'], 3)} -> ratio {np.round(st['ratio'], 3)}, "
           f"block ratio {np.round(st['block_ratio'], 3)}, |mean diff| / sigma {np.round(st['dmean'] / st['sigma'], 2)}")
     assert (st["floor"] > 0).all()
