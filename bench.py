@@ -78,20 +78,27 @@ def kernel_source_sha256():
 
 
 def pmc_counters(config, kernel):
-    """The rocprofv3 PMC figures of `kernel` on `config` from the newest profiles/*_pmc.json (made by tools/pmc_summarise.py), or
+    """The rocprofv3 PMC figures of `kernel` on `config` from profiles/*_pmc.json (made by tools/pmc_summarise.py), or
     None.  `stale`: the file was collected on other kernel sources than the ones here (or does not say)."""
     d = os.path.join(ROOT, "profiles")
     files = sorted(f for f in os.listdir(d) if f.endswith("_pmc.json")) if os.path.isdir(d) else []
     if not files:
         return None
-    with open(os.path.join(d, files[-1])) as fh:
-        doc = json.load(fh)
+    # the collection made on the kernel sources that are here, if there is one; else the last by name (stale)
+    docs = []
+    for f in files:
+        with open(os.path.join(d, f)) as fh:
+            docs.append((f, json.load(fh)))
+    sha = kernel_source_sha256()
+    match = [fd for fd in docs if fd[1].get("kernel_source_sha256") == sha]
+    name, doc = (match or docs)[-1]
+    files = [name]
     rec = doc.get("configs", {}).get(config, {}).get("kernels", {}).get(kernel)
     if rec is None:
         return None
     out = {k: rec[k] for k in ("valu_busy", "wait_share", "l2_hit_rate", "hbm_bytes_per_segment", "hbm_gbps", "valu_lane_slots_per_segment") if k in rec}
     out["source"] = "profiles/" + files[-1]
-    out["stale"] = doc.get("kernel_source_sha256") != kernel_source_sha256()
+    out["stale"] = doc.get("kernel_source_sha256") != sha
     return out
 
 
