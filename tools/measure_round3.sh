@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU session: everything the round's numbers come from, on one build.  Tag = first argument.
+# GPU session: every measurement that is reported (tests, counters, bench lines, kernel trace, rank rehearsals, split emulation), on one build.  Tag = first argument.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=${1:-r03o}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU session: everything the round's numbers come from, on one build, counters first so that the bench lines carry the
+# GPU session: every measurement that is reported (tests, counters, bench lines, kernel trace, rank rehearsals, split emulation), on one build, counters first so that the bench lines carry the
 # counters of the build they run (bench.py reads the newest profiles/*_pmc.json).  Tag = first argument.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
